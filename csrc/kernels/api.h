@@ -1,0 +1,141 @@
+// Plain-C launch interface of the gfx950 kernel library.  Included by the device translation units
+// and by the host-only torch binding, so it contains no HIP device types.
+// Every launcher enqueues on `stream` (a hipStream_t passed as void*), never synchronises and never
+// allocates, so a caller may capture it into a hipGraph.  Return value: 0 on success, otherwise a
+// negative argument-check code or a positive hipError_t.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PDT_F16 = 0, PDT_BF16 = 1 };
+
+typedef struct PdtRng {
+  const uint64_t* state;  // device memory: state[0] = seed, state[1] = optimizer-step offset
+  uint32_t micro;         // micro-batch index inside the step
+  uint32_t stream;        // dropout site id
+} PdtRng;
+
+// ---- GEMM -------------------------------------------------------------------------------------
+enum { PDT_EPI_PLAIN = 0, PDT_EPI_BIAS = 1, PDT_EPI_BIAS_GELU = 2, PDT_EPI_BIAS_DROP_RES = 3,
+       PDT_EPI_MUL_DGELU = 4, PDT_EPI_ADD_RES = 5, PDT_EPI_SLAB_F32 = 6, PDT_EPI_BIAS_TANH = 7 };
+// operand layouts: NT: A[M,K] B[N,K];  NN: A[M,K] B[K,N];  TN: A[K,M] B[K,N]
+enum { PDT_GEMM_NT = 0, PDT_GEMM_NN = 1, PDT_GEMM_TN = 2 };
+
+typedef struct PdtGemm {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int epi;
+  const void* bias;
+  const void* res;
+  int ldr;
+  void* aux;
+  int ldaux;
+  float drop_scale;
+  uint32_t drop_thr;
+  PdtRng rng;
+  int k_per_split;
+  int tiles_m, tiles_n, splits;
+} PdtGemm;
+
+// tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves), -1 = choose from the shape.
+// For TN, C is the fp32 slab buffer [splits][M][ldc] and g->splits / k_per_split select the K split
+// (0 = choose); the chosen values are written back into *g.
+int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]   (out fp32; n multiple of 4)
+int pdt_splitk_reduce(const float* slab, int splits, int64_t n, float* out, int accumulate, void* stream);
+int pdt_gemm_max_splits(void);
+
+// ---- LayerNorm ----------------------------------------------------------------------------------
+// y = LN(x) * gamma + beta ; stats[row] = {mean, rstd}.  H multiple of 8, H <= 8192.
+int pdt_layernorm_fwd(int dtype, const void* x, const void* gamma, const void* beta, void* y, float* stats,
+                      int rows, int H, float eps, void* stream);
+// dx (16-bit) = LN backward wrt x;  ddrop (optional, 16-bit) = dx with the dropout mask of `rng` applied
+// (gradient wrt the pre-dropout tensor);  partial[nblk][3][H] fp32 column partial sums of
+// {dy*xhat, dy, ddrop-or-dx}.  Returns the number of partial blocks through *nblk.
+int pdt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const void* gamma,
+                      void* dx, void* ddrop, float* partial, int* nblk, int rows, int H,
+                      float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+int pdt_layernorm_bwd_max_blocks(void);
+// partial is [nblk][nseg][H]; out_j[c] (+)= sum_b partial[b][j][c] for each non-null out_j (nseg <= 4)
+int pdt_colsum_finish(const float* partial, int nblk, int H, int nseg, float* o0, float* o1, float* o2, float* o3,
+                      int accumulate, void* stream);
+// partial[nblk][ncols] column sums of a 16-bit [rows, ld] matrix (bias gradients)
+int pdt_colsum_partial(int dtype, const void* x, int rows, int ncols, int ld, float* partial, int* nblk, void* stream);
+
+// ---- Embeddings -----------------------------------------------------------------------------------
+// y = dropout(LN(word[ids] + pos[pos_ids] + type[type_ids]));  pre = the LN input (saved for backward)
+int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                  const void* inputs_embeds, const void* word, const void* pos, const void* type,
+                  const void* gamma, const void* beta, void* pre, void* y, float* stats, int tokens, int H,
+                  float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+// scatter-add rows of d (16-bit [tokens,H]) into the fp32 tables gw[ids] (skipping `pad_id`) and
+// gp[pos_ids] with fp32 atomics; either table may be null
+int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw, float* gp,
+                      int tokens, int H, int64_t pad_id, void* stream);
+// token-type table gradient (R <= 4 rows) as deterministic masked column partial sums partial[nblk][R][H]
+// (finish with pdt_colsum_finish, nseg = R)
+int pdt_embed_type_partial(int dtype, const void* d, const int64_t* type_ids, float* partial, int* nblk, int tokens,
+                           int H, int R, void* stream);
+// apply the dropout mask of `rng` to a 16-bit [n] tensor: y = keep ? x*scale : 0
+int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, float drop_scale, uint32_t drop_thr,
+                      PdtRng rng, void* stream);
+
+// ---- Attention -------------------------------------------------------------------------------------
+// qkv: 16-bit [B*S, 3H] (Q | K | V, head h at columns h*64 of each third); mask int32 [B,S];
+// kv_len int32 [B]; ctx 16-bit [B*S, H]; lse fp32 [B, A, S].  head_dim == 64, S <= 512.
+int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, void* ctx, float* lse,
+                 int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+// dqkv 16-bit [B*S, 3H];  delta fp32 [B,A,S] scratch
+int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const void* ctx,
+                 const void* dctx, const float* lse, float* delta, void* dqkv, int B, int S, int A,
+                 float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+
+// ---- Classification head ------------------------------------------------------------------------------
+// logits[b][c] = dot(dropout(pooled[b]), W[c]) + bias[c]; loss[0] = mean CE.  pooled 16-bit [B,H];
+// W, bias, logits, loss fp32; C <= 8; labels may be null (no loss)
+int pdt_head_fwd(int dtype, const void* pooled, const float* W, const float* bias, const int64_t* labels,
+                 float* logits, float* loss, int B, int H, int C, float drop_scale, uint32_t drop_thr, PdtRng rng,
+                 void* stream);
+// gloss[0] = upstream gradient of the mean loss.  dpooled 16-bit [B,H] (times 1-pooled^2 when tanh_bwd);
+// dW [C,H], dbias [C] fp32 (+= when accumulate)
+int pdt_head_bwd(int dtype, const void* pooled, const float* W, const float* logits, const int64_t* labels,
+                 const float* gloss, void* dpooled, float* dW, float* dbias, int B, int H, int C, float drop_scale,
+                 uint32_t drop_thr, PdtRng rng, int accumulate, int tanh_bwd, void* stream);
+
+// ---- Optimizer ----------------------------------------------------------------------------------------
+typedef struct PdtAdamW {
+  float* p;          // fp32 master parameters
+  float* m;
+  float* v;
+  const float* g;    // fp32 gradients (possibly loss-scaled)
+  void* p16;         // 16-bit compute copy (may be null)
+  int64_t n;
+  float beta1, beta2, eps, weight_decay;
+  int correct_bias;
+  // device scalars: lr[0]; step[0] (int32, incremented by pdt_scaler_update); scale_state = {scale,
+  // growth_tracker(as float), found_inf}
+  const float* lr;
+  const int32_t* step;
+  float* scale_state;
+} PdtAdamW;
+// found_inf |= any(!isfinite(g))  (scale_state[2])
+int pdt_grad_check(const float* g, int64_t n, float* scale_state, void* stream);
+// p,m,v,p16 update with g/scale, skipped entirely when found_inf is set
+int pdt_adamw_step(int dtype, const PdtAdamW* a, void* stream);
+// dynamic loss-scale update + step counter: on overflow scale*=backoff, tracker=0, step unchanged;
+// else tracker++ (scale*=growth every `interval` clean steps), step++.  Clears found_inf.
+int pdt_scaler_update(float* scale_state, int32_t* step, float growth, float backoff, int interval,
+                      int dynamic, void* stream);
+// 16-bit copy of fp32 values (initial cast of the master arena)
+int pdt_cast_f32_to_16(int dtype, const float* src, void* dst, int64_t n, void* stream);
+int pdt_fill_f32(float* dst, float value, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,133 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of this framework.
+// Everything here is written for 64-wide wavefronts and the gfx950 MFMA / LDS instruction set.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "api.h"
+
+namespace pdt {
+
+typedef short short8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4r __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define PDT_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+
+// dtype codes shared with the host side
+enum : int { DT_F16 = 0, DT_BF16 = 1 };
+
+// ---------------------------------------------------------------------------------------
+// 16-bit float traits: raw 16-bit lanes travel as `short`, math is always fp32.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Half16;
+template <> struct Half16<_Float16> {
+  static constexpr int code = DT_F16;
+  static __device__ __forceinline__ float to_f(short s) { return (float)__builtin_bit_cast(_Float16, s); }
+  static __device__ __forceinline__ short from_f(float f) { return __builtin_bit_cast(short, (_Float16)f); }
+  static __device__ __forceinline__ float4v mfma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Half16<__bf16> {
+  static constexpr int code = DT_BF16;
+  static __device__ __forceinline__ float to_f(short s) {
+    return __builtin_bit_cast(float, ((uint32_t)(uint16_t)s) << 16);
+  }
+  static __device__ __forceinline__ short from_f(float f) { return __builtin_bit_cast(short, (__bf16)f); }
+  static __device__ __forceinline__ float4v mfma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ void unpack8(short8 v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = Half16<T>::to_f(v[i]);
+}
+template <typename T> __device__ __forceinline__ short8 pack8(const float (&f)[8]) {
+  short8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = Half16<T>::from_f(f[i]);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based RNG (Philox4x32-10).  A dropout mask is a pure function of
+// (seed, offset, stream, element index): the backward pass regenerates it instead of storing it,
+// and it does not depend on how a kernel maps elements to lanes.
+// ---------------------------------------------------------------------------------------
+using RngArgs = PdtRng;  // {device state {seed, step offset}, micro-batch index, dropout-site id}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint2 key, uint4 ctr) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+
+struct DropKey {
+  uint2 key;
+  uint32_t stream, micro;
+};
+__device__ __forceinline__ DropKey drop_key(const RngArgs& r) {
+  uint64_t seed = r.state[0], off = r.state[1];
+  uint64_t mixed = seed ^ (off * 0x9E3779B97F4A7C15ull);
+  DropKey k;
+  k.key = make_uint2((uint32_t)mixed, (uint32_t)(mixed >> 32));
+  k.stream = r.stream;
+  k.micro = r.micro;
+  return k;
+}
+// keep-bits for the 8 elements of group `g` (element index / 8): bit i set => element kept.
+// thr16 = round(p * 65536): an element is dropped when its 16-bit draw is < thr16.
+__device__ __forceinline__ uint32_t drop_keep8(const DropKey& k, uint64_t g, uint32_t thr16) {
+  uint4 r = philox4x32_10(k.key, make_uint4((uint32_t)g, (uint32_t)(g >> 32), k.stream, k.micro));
+  uint32_t w[4] = {r.x, r.y, r.z, r.w};
+  uint32_t bits = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bits |= ((w[i] & 0xFFFFu) >= thr16 ? 1u : 0u) << (2 * i);
+    bits |= ((w[i] >> 16) >= thr16 ? 1u : 0u) << (2 * i + 1);
+  }
+  return bits;
+}
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+  float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (and its
+// L2), so give each XCD a contiguous run of tiles.  Pure speed lever, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace pdt

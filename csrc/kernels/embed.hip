@@ -1,0 +1,171 @@
+// Embedding kernels: fused gather(word,pos,type) + add + LayerNorm + dropout forward, and the
+// gradient scatter into the fp32 tables.  One wave per token, 16 B per lane.
+#include "common.hpp"
+
+namespace pdt {
+
+constexpr int EMB_MAX_CHUNKS = 4;  // H <= 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                        const int64_t* __restrict__ type_ids, const T* __restrict__ inputs_embeds,
+                                                        const T* __restrict__ word, const T* __restrict__ pos,
+                                                        const T* __restrict__ type, const T* __restrict__ gamma,
+                                                        const T* __restrict__ beta, T* __restrict__ pre, T* __restrict__ y,
+                                                        float* __restrict__ stats, int tokens, int H, float eps,
+                                                        float drop_scale, uint32_t drop_thr, RngArgs rng) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const int nchunk = H >> 3;
+  const T* wrow = inputs_embeds ? inputs_embeds + (size_t)tok * H : word + (size_t)ids[tok] * H;
+  const T* prow = pos + (size_t)pos_ids[tok] * H;
+  const T* trow = type + (size_t)type_ids[tok] * H;
+  float v[EMB_MAX_CHUNKS][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float a[8], b[8], d[8];
+      unpack8<T>(*reinterpret_cast<const short8*>(wrow + c * 8), a);
+      unpack8<T>(*reinterpret_cast<const short8*>(prow + c * 8), b);
+      unpack8<T>(*reinterpret_cast<const short8*>(trow + c * 8), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = a[j] + b[j] + d[j];
+      // the backward pass normalises the stored 16-bit copy, so the statistics use the same values
+      const short8 packed = pack8<T>(v[i]);
+      *reinterpret_cast<short8*>(pre + (size_t)tok * H + c * 8) = packed;
+      unpack8<T>(packed, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+  }
+  const float mean = wave_sum(sum) / H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / H + eps);
+  if (lane == 0) { stats[2 * tok] = mean; stats[2 * tok + 1] = rstd; }
+  DropKey dk = drop_key(rng);
+#pragma unroll
+  for (int i = 0; i < EMB_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float g[8], b[8], o[8];
+      unpack8<T>(*reinterpret_cast<const short8*>(gamma + c * 8), g);
+      unpack8<T>(*reinterpret_cast<const short8*>(beta + c * 8), b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      if (drop_thr != 0) {
+        const uint32_t keep = drop_keep8(dk, ((uint64_t)tok * H + c * 8) >> 3, drop_thr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? o[j] * drop_scale : 0.f;
+      }
+      *reinterpret_cast<short8*>(y + (size_t)tok * H + c * 8) = pack8<T>(o);
+    }
+  }
+}
+
+// Word / position rows: fp32 atomic adds, 256 contiguous bytes per wave-instruction (one dword per lane).
+// The padding row of the word table receives no gradient (nn.Embedding padding_idx semantics).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ d, const int64_t* __restrict__ ids,
+                                                            const int64_t* __restrict__ pos_ids, float* __restrict__ gw,
+                                                            float* __restrict__ gp, int tokens, int H, int64_t pad_id) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const int64_t id = ids ? ids[tok] : -1;
+  float* wrow = (gw && ids && id != pad_id) ? gw + (size_t)id * H : nullptr;
+  float* prow = gp ? gp + (size_t)pos_ids[tok] * H : nullptr;
+  for (int c = lane; c < H; c += 64) {
+    const float v = Half16<T>::to_f(reinterpret_cast<const short*>(d)[(size_t)tok * H + c]);
+    if (wrow) atomicAdd(wrow + c, v);
+    if (prow) atomicAdd(prow + c, v);
+  }
+}
+
+// Token-type table (<= 4 rows): masked column sums, deterministic.  partial[nblk][R][H]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_type_partial_kernel(const T* __restrict__ d, const int64_t* __restrict__ type_ids,
+                                                                 float* __restrict__ partial, int tokens, int H, int R,
+                                                                 int rows_per_blk) {
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (col >= H) return;
+  const int r0 = blockIdx.y * rows_per_blk, r1 = min(tokens, r0 + rows_per_blk);
+  float acc[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+  for (int t = r0; t < r1; ++t) {
+    float v[8];
+    unpack8<T>(*reinterpret_cast<const short8*>(d + (size_t)t * H + col), v);
+    const int ty = (int)type_ids[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r == ty)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] += v[j];
+  }
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) partial[((size_t)blockIdx.y * R + r) * H + col + j] = acc[r][j];
+}
+
+}  // namespace pdt
+
+using namespace pdt;
+
+extern "C" int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                             const void* inputs_embeds, const void* word, const void* pos, const void* type,
+                             const void* gamma, const void* beta, void* pre, void* y, float* stats, int tokens, int H,
+                             float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
+  if ((H & 7) || H > EMB_MAX_CHUNKS * 512 || tokens <= 0) return -3;
+  if (!ids && !inputs_embeds) return -2;
+  const dim3 grid((tokens + 3) / 4), block(256);
+#define PDT_GO(TT)                                                                                                   \
+  hipLaunchKernelGGL(embed_fwd_kernel<TT>, grid, block, 0, (hipStream_t)stream, ids, pos_ids, type_ids,               \
+                     (const TT*)inputs_embeds, (const TT*)word, (const TT*)pos, (const TT*)type, (const TT*)gamma,    \
+                     (const TT*)beta, (TT*)pre, (TT*)y, stats, tokens, H, eps, drop_scale, drop_thr, rng)
+  if (dtype == PDT_F16) PDT_GO(_Float16); else PDT_GO(__bf16);
+#undef PDT_GO
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw,
+                                 float* gp, int tokens, int H, int64_t pad_id, void* stream) {
+  if (tokens <= 0) return -3;
+  const dim3 grid((tokens + 3) / 4), block(256);
+  if (dtype == PDT_F16)
+    hipLaunchKernelGGL(embed_scatter_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16*)d, ids,
+                       pos_ids, gw, gp, tokens, H, pad_id);
+  else
+    hipLaunchKernelGGL(embed_scatter_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)d, ids,
+                       pos_ids, gw, gp, tokens, H, pad_id);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_embed_type_partial(int dtype, const void* d, const int64_t* type_ids, float* partial, int* nblk,
+                                      int tokens, int H, int R, void* stream) {
+  if ((H & 7) || R < 1 || R > 4 || tokens <= 0) return -3;
+  int rpb = 64;
+  int nb = (tokens + rpb - 1) / rpb;
+  if (nb > 256) { rpb = (tokens + 255) / 256; nb = (tokens + rpb - 1) / rpb; }
+  *nblk = nb;
+  const dim3 grid((H / 8 + 255) / 256, nb), block(256);
+  if (dtype == PDT_F16)
+    hipLaunchKernelGGL(embed_type_partial_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16*)d,
+                       type_ids, partial, tokens, H, R, rpb);
+  else
+    hipLaunchKernelGGL(embed_type_partial_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)d,
+                       type_ids, partial, tokens, H, R, rpb);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,274 @@
+// MFMA GEMM for gfx950: C[M,N] = sum_k A(m,k) * B(n,k) with fused epilogues.
+//
+// Operand storage (per operand, compile-time):
+//   K-contiguous : X stored [rows, ld], element (x,k) at X[x*ld + k]   (activations, Linear weights in fwd)
+//   K-strided    : X stored [K, ld],    element (x,k) at X[k*ld + x]   (weights in dgrad, both operands in wgrad)
+// so forward (X*W^T), dgrad (dY*W) and wgrad (dY^T*X) all run on this one kernel with no transposed copies.
+//
+// Structure: BK=64 K-tiles, direct-to-LDS loads (buffer_load ... lds, 16 B/lane) into two LDS stages,
+// one barrier per K-tile; 16x16x32 MFMA; XOR-swizzled LDS images so that ds_read_b128 (K-contiguous)
+// and ds_read_b64_tr_b16 (K-strided) fragment reads are bank-conflict free; the swizzle is applied on the
+// per-lane SOURCE address because an LDS-DMA write is lane-linear.  The accumulator tile leaves through a
+// wave-private fp32 LDS transpose so that every global store / residual load is 16 B per lane on full
+// 128-B row segments.
+#pragma once
+#include "common.hpp"
+
+namespace pdt {
+
+enum GemmEpilogue : int {
+  EPI_PLAIN = PDT_EPI_PLAIN,                  // C = acc
+  EPI_BIAS = PDT_EPI_BIAS,                    // C = acc + bias[n]
+  EPI_BIAS_GELU = PDT_EPI_BIAS_GELU,          // aux = acc + bias[n] ; C = gelu(aux)
+  EPI_BIAS_DROP_RES = PDT_EPI_BIAS_DROP_RES,  // C = dropout(acc + bias[n]) + res[m,n]
+  EPI_MUL_DGELU = PDT_EPI_MUL_DGELU,          // C = acc * gelu'(aux[m,n])
+  EPI_ADD_RES = PDT_EPI_ADD_RES,              // C = acc + res[m,n]
+  EPI_SLAB_F32 = PDT_EPI_SLAB_F32,            // split-K partial: fp32 slab[split][m,n] = acc
+  EPI_BIAS_TANH = PDT_EPI_BIAS_TANH,          // C = tanh(acc + bias[n])
+};
+using GemmArgs = PdtGemm;
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS>
+struct GemmKernel {
+  static constexpr int NT = WAVES_M * WAVES_N * 64;
+  static constexpr int BK = 64;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  static constexpr int FM = WTM / 16, FN = WTN / 16;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int A_PASSES = A_BYTES / (NT * 16), B_PASSES = B_BYTES / (NT * 16);
+  static_assert(WTN == 64, "staged epilogue assumes 64 output columns per wave");
+  static_assert(A_BYTES % (NT * 16) == 0 && B_BYTES % (NT * 16) == 0, "tile/threads mismatch");
+  static_assert(WAVES_M * WAVES_N * 32 * 256 <= LDS_BYTES, "epilogue staging does not fit");
+
+  // swizzle key of a K-strided image row k (32-B chunk index XOR): distinct for the 8 rows one
+  // half-wave touches in a transposed read {4 consecutive k} x {two k-groups 8 apart}
+  static __device__ __forceinline__ int ks_key(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+  // ---- per-lane source offsets for one operand -------------------------------------------------
+  template <bool KS, int BX, int PASSES>
+  struct Loader {
+    uint32_t off[PASSES];    // byte offset of this lane's 16 B inside the operand's buffer window
+    uint32_t kcol[PASSES];   // (K-contiguous only) k index of the chunk inside the K-tile
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t kstep;          // bytes to advance per K-tile
+
+    __device__ __forceinline__ void init(const T* X, int ld, int xdim, int x0, int kb, int klen, int tid) {
+      constexpr int pitch = BX * 2;  // K-strided image row pitch (bytes)
+      const T* base;
+      uint32_t records;
+      const int xavail = min(BX, xdim - x0);
+      if (KS) {
+        base = X + (size_t)kb * ld + x0;
+        records = (uint32_t)(((size_t)(klen - 1) * ld + xavail) * 2);
+        kstep = (uint32_t)ld * 2u * BK;
+      } else {
+        base = X + (size_t)x0 * ld + kb;
+        records = (uint32_t)(((size_t)(xavail - 1) * ld + klen) * 2);
+        kstep = BK * 2;
+      }
+      rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int pos = p * NT * 16 + tid * 16;
+        if (KS) {
+          const int k = pos / pitch, w = pos % pitch;
+          const int chunk = (w >> 5) ^ ks_key(k);
+          const int col = chunk * 16 + ((w >> 4) & 1) * 8;
+          const bool ok = (col + 8 <= xavail);
+          off[p] = ok ? (uint32_t)k * ld * 2u + col * 2u : 0x80000000u;
+          kcol[p] = 0;
+        } else {
+          const int row = pos >> 7, cpos = (pos >> 4) & 7;
+          const int c = cpos ^ (row & 7);
+          const bool ok = row < xavail;
+          off[p] = ok ? (uint32_t)row * ld * 2u + c * 16u : 0x80000000u;
+          kcol[p] = c * 8;
+        }
+      }
+    }
+    // issue this operand's LDS-DMA loads for K-tile `kt` into `dst` (wave-uniform LDS base of the image)
+    __device__ __forceinline__ void issue(char* dst, int kt, int klen, int wave) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        uint32_t o = off[p] + (uint32_t)kt * kstep;
+        if (!KS) o = ((int)(kcol[p] + kt * BK) < klen) ? o : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(dst + p * NT * 16 + wave * 1024), 16, o, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment reads ----------------------------------------------------------------------------
+  // K-contiguous image [BX][64] (128-B rows): 8 k-values of row x0+(lane&15), k-group (lane>>4) of k-step ks
+  static __device__ __forceinline__ short8 frag_kc(const char* img, int x0, int ks, int lane) {
+    const int row = x0 + (lane & 15);
+    const int chunk = (ks * 4 + (lane >> 4)) ^ (row & 7);
+    return *reinterpret_cast<const short8*>(img + row * 128 + chunk * 16);
+  }
+  // K-strided image [64][BX]: two transposed 4x16 reads give the same 8 k-values for column x0+(lane&15)
+  template <int BX>
+  static __device__ __forceinline__ short8 frag_ks(const char* img, int x0, int ks, int lane) {
+    constexpr int pitch = BX * 2;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int key = q | ((g & 1) << 2);
+    const int chunk = (x0 >> 4) ^ key;
+    const int k = ks * 32 + g * 8 + q;
+    const char* a = img + k * pitch + chunk * 32 + p * 8;
+    short4r lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4r __attribute__((address_space(3)))*)PDT_LDS_PTR(a));
+    short4r hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4r __attribute__((address_space(3)))*)PDT_LDS_PTR(a + 4 * pitch));
+    short8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+
+  // ---- epilogue on 8 consecutive columns of one row ---------------------------------------------
+  static __device__ __forceinline__ void epilogue8(const GemmArgs& g, int m, int n, float (&v)[8], const DropKey& dk) {
+    const int epi = g.epi;
+    if (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_TANH) {
+      float b[8];
+      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.bias + n), b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += b[i];
+    }
+    if (epi == EPI_BIAS_GELU) {
+      *reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n) = pack8<T>(v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+    } else if (epi == EPI_BIAS_TANH) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
+    } else if (epi == EPI_MUL_DGELU) {
+      float u[8];
+      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.aux + (size_t)m * g.ldaux + n), u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
+    }
+    if (epi == EPI_BIAS_DROP_RES && g.drop_thr != 0) {
+      const uint32_t keep = drop_keep8(dk, ((uint64_t)m * g.N + n) >> 3, g.drop_thr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * g.drop_scale : 0.0f;
+    }
+    if (epi == EPI_BIAS_DROP_RES || epi == EPI_ADD_RES) {
+      float r[8];
+      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.res + (size_t)m * g.ldr + n), r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += r[i];
+    }
+    *reinterpret_cast<short8*>((T*)g.C + (size_t)m * g.ldc + n) = pack8<T>(v);
+  }
+
+  static __device__ __forceinline__ void run(const GemmArgs& g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int ntiles = g.tiles_m * g.tiles_n;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id / ntiles, t = id % ntiles;
+    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kb = split * g.k_per_split;
+    const int klen = min(g.K - kb, g.k_per_split);
+    const int nkt = (klen + BK - 1) / BK;
+
+    Loader<AKS, BM, A_PASSES> la;
+    Loader<BKS, BN, B_PASSES> lb;
+    la.init((const T*)g.A, g.lda, g.M, m0, kb, klen, tid);
+    lb.init((const T*)g.B, g.ldb, g.N, n0, kb, klen, tid);
+
+    float4v acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    la.issue(smem, 0, klen, wave);
+    lb.issue(smem + A_BYTES, 0, klen, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      char* st = smem + cur * STAGE_BYTES;
+      if (kt + 1 < nkt) {
+        char* nx = smem + (cur ^ 1) * STAGE_BYTES;
+        la.issue(nx, kt + 1, klen, wave);
+        lb.issue(nx + A_BYTES, kt + 1, klen, wave);
+      }
+      const char* ia = st;
+      const char* ib = st + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        short8 fa[FM], fb[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          fb[j] = BKS ? frag_ks<BN>(ib, wn * WTN + j * 16, ks, lane) : frag_kc(ib, wn * WTN + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          fa[i] = AKS ? frag_ks<BM>(ia, wm * WTM + i * 16, ks, lane) : frag_kc(ia, wm * WTM + i * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            // MFMA "A" operand = B-matrix rows (n), "B" operand = A-matrix rows (m):
+            // D[n][m] => lane holds m = lane&15 and 4 consecutive n = 4*(lane>>4)+r
+            acc[i][j] = Half16<T>::mfma(fb[j], fa[i], acc[i][j]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int lm = lane & 15, lg = lane >> 4;
+    if (g.epi == EPI_SLAB_F32) {
+      float* slab = (float*)g.C + (size_t)split * g.M * g.ldc;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + lm;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + wn * WTN + j * 16 + lg * 4;
+          if (m < g.M && n < g.N) *reinterpret_cast<float4v*>(slab + (size_t)m * g.ldc + n) = acc[i][j];
+        }
+      }
+      return;
+    }
+    DropKey dk = drop_key(g.rng);
+    // wave-private 32-row x 64-col fp32 staging, 16-B chunks XOR-swizzled by (row & 15)
+    char* stg = smem + wave * (32 * 256);
+#pragma unroll
+    for (int ip = 0; ip < FM / 2; ++ip) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + lm;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int chunk = (j * 4 + lg) ^ lm;
+          *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
+        }
+      }
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {  // not unrolled: the epilogue math is emitted once per row pair
+        const int row = it * 8 + (lane >> 3), jc = lane & 7;
+        const int key = row & 15;
+        const float4v lo = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
+        const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int m = m0 + wm * WTM + ip * 32 + row;
+        const int n = n0 + wn * WTN + jc * 8;
+        if (m < g.M && n < g.N) epilogue8(g, m, n, v, dk);
+      }
+    }
+  }
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs g) {
+  GemmKernel<T, BM, BN, WAVES_M, WAVES_N, AKS, BKS>::run(g);
+}
+
+}  // namespace pdt

@@ -1,0 +1,69 @@
+// Host-side GEMM dispatch: argument checks, tile / split-K selection, split-K reduction kernel.
+#include "common.hpp"
+
+extern "C" int pdt_gemm_nt(int dtype, int tile, PdtGemm* g, void* stream);
+extern "C" int pdt_gemm_nn(int dtype, int tile, PdtGemm* g, void* stream);
+extern "C" int pdt_gemm_tn(int dtype, int tile, PdtGemm* g, void* stream);
+
+namespace pdt {
+constexpr int kMaxSplits = 32;
+constexpr int kNumCU = 256;
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n4,
+                                                            float* __restrict__ out, int accumulate) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4v s = accumulate ? reinterpret_cast<const float4v*>(out)[i] : float4v{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) s += reinterpret_cast<const float4v*>(slab)[(int64_t)k * n4 + i];
+    reinterpret_cast<float4v*>(out)[i] = s;
+  }
+}
+}  // namespace pdt
+
+extern "C" int pdt_gemm_max_splits(void) { return pdt::kMaxSplits; }
+
+extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream) {
+  using namespace pdt;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return -2;
+  if ((g->N & 7) || (g->lda & 7) || (g->ldb & 7) || (g->ldc & 7)) return -3;  // 16-B vector access
+  if (layout != PDT_GEMM_TN && (g->K & 7)) return -3;
+  if (layout == PDT_GEMM_TN && (g->M & 7)) return -3;
+  // operand windows are addressed with 32-bit byte offsets; 0x80000000 marks an out-of-range lane
+  const int64_t a_bytes = 2ll * (layout == PDT_GEMM_TN ? (int64_t)g->K * g->lda : 256ll * g->lda);
+  const int64_t b_bytes = 2ll * (layout == PDT_GEMM_NT ? 256ll * g->ldb : (int64_t)g->K * g->ldb);
+  if (a_bytes >= 0x7FFF0000ll || b_bytes >= 0x7FFF0000ll) return -4;
+  if (tile < 0) {
+    // 256x256 tiles (one workgroup per CU) once they fill the chip, else 128x128 at 2 workgroups per CU
+    const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
+    tile = (t256 >= 160 || layout == PDT_GEMM_TN) ? 1 : 0;
+    if (layout == PDT_GEMM_TN && (g->M < 256 || g->N < 256)) tile = 0;
+  }
+  if (layout == PDT_GEMM_TN) {
+    if (g->epi != PDT_EPI_SLAB_F32) return -5;
+    const int bt = tile == 1 ? 256 : 128;
+    const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
+    const int ktiles = (g->K + 63) / 64;
+    if (g->splits <= 0) {
+      const int target = tile == 1 ? kNumCU : 2 * kNumCU;
+      int s = (target + tiles - 1) / tiles;
+      s = s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s);
+      if (s > ktiles) s = ktiles;
+      g->splits = s;
+    }
+    const int kt_per = (ktiles + g->splits - 1) / g->splits;
+    g->k_per_split = kt_per * 64;
+    g->splits = (ktiles + kt_per - 1) / kt_per;  // no empty split
+    return pdt_gemm_tn(dtype, tile, g, stream);
+  }
+  if (g->epi == PDT_EPI_SLAB_F32) return -5;
+  return layout == PDT_GEMM_NT ? pdt_gemm_nt(dtype, tile, g, stream) : pdt_gemm_nn(dtype, tile, g, stream);
+}
+
+extern "C" int pdt_splitk_reduce(const float* slab, int splits, int64_t n, float* out, int accumulate, void* stream) {
+  if (n & 3) return -3;
+  const int64_t n4 = n >> 2;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pdt::splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, splits, n4, out, accumulate);
+  return (int)hipGetLastError();
+}

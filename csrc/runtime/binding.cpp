@@ -1,0 +1,490 @@
+// Torch-facing runtime of the gfx950 kernel library: tensor checks, stream plumbing, and the fused
+// encoder-layer forward/backward that chains the kernels (the per-layer "schedule" lives here in C++,
+// so one Python call issues all launches of a layer on the current HIP stream).
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../kernels/api.h"
+
+namespace py = pybind11;
+using at::Tensor;
+
+namespace {
+
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+
+int dt_code(const Tensor& t) {
+  if (t.scalar_type() == at::kHalf) return PDT_F16;
+  if (t.scalar_type() == at::kBFloat16) return PDT_BF16;
+  TORCH_CHECK(false, "expected a float16/bfloat16 tensor, got ", t.scalar_type());
+}
+void check(int err, const char* what) {
+  TORCH_CHECK(err == 0, "pdt kernel launch failed in ", what, ": code ", err,
+              err < 0 ? " (argument check)" : " (hipError_t)");
+}
+void chk16(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be on the GPU");
+  TORCH_CHECK(t.scalar_type() == at::kHalf || t.scalar_type() == at::kBFloat16, name, " must be 16-bit float");
+  TORCH_CHECK(t.stride(-1) == 1, name, " must have unit inner stride");
+  TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0, name, " must be 16-byte aligned");
+}
+void chkf32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous(), name,
+              " must be a contiguous fp32 GPU tensor");
+}
+uint32_t thr16(double p) { return p <= 0.0 ? 0u : (uint32_t)std::lround(p * 65536.0); }
+float keep_scale(double p) { return p <= 0.0 ? 1.0f : (float)(1.0 / (1.0 - p)); }
+
+PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site) {
+  TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kLong && state.numel() >= 2, "rng state: int64[2] on GPU");
+  return PdtRng{reinterpret_cast<const uint64_t*>(state.data_ptr<int64_t>()), (uint32_t)micro, (uint32_t)site};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GEMM wrappers.  2-D operands; leading dimension = stride(0).
+// ---------------------------------------------------------------------------------------------------
+struct Epi {
+  int kind = PDT_EPI_PLAIN;
+  const Tensor* bias = nullptr;
+  const Tensor* res = nullptr;
+  Tensor* aux = nullptr;
+  double drop_p = 0.0;
+  PdtRng rng{nullptr, 0, 0};
+};
+
+void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, int N, int K, const Epi& e, int tile = -1) {
+  PdtGemm g{};
+  g.A = A.data_ptr(); g.B = B.data_ptr(); g.C = C.data_ptr();
+  g.M = M; g.N = N; g.K = K;
+  g.lda = (int)A.stride(0); g.ldb = (int)B.stride(0); g.ldc = (int)C.stride(0);
+  g.epi = e.kind;
+  if (e.bias) { chk16(*e.bias, "bias"); g.bias = e.bias->data_ptr(); }
+  if (e.res) { chk16(*e.res, "res"); g.res = e.res->data_ptr(); g.ldr = (int)e.res->stride(0); }
+  if (e.aux) { chk16(*e.aux, "aux"); g.aux = e.aux->data_ptr(); g.ldaux = (int)e.aux->stride(0); }
+  g.drop_thr = thr16(e.drop_p);
+  g.drop_scale = keep_scale(e.drop_p);
+  g.rng = e.rng;
+  check(pdt_gemm(dt_code(A), layout, tile, &g, cur_stream()), "gemm");
+}
+
+// C[M,N] = A[M,K] * W[N,K]^T (+ epilogue)
+Tensor gemm_nt(const Tensor& A, const Tensor& W, const Epi& e, int tile = -1) {
+  chk16(A, "A"); chk16(W, "W");
+  const int M = (int)A.size(0), K = (int)A.size(1), N = (int)W.size(0);
+  TORCH_CHECK(W.size(1) == K, "gemm_nt: inner dims differ");
+  Tensor C = at::empty({M, N}, A.options());
+  run_gemm(PDT_GEMM_NT, A, W, C, M, N, K, e, tile);
+  return C;
+}
+// C[M,N] = A[M,K] * W[K,N] (+ epilogue)
+Tensor gemm_nn(const Tensor& A, const Tensor& W, const Epi& e, int tile = -1) {
+  chk16(A, "A"); chk16(W, "W");
+  const int M = (int)A.size(0), K = (int)A.size(1), N = (int)W.size(1);
+  TORCH_CHECK(W.size(0) == K, "gemm_nn: inner dims differ");
+  Tensor C = at::empty({M, N}, A.options());
+  run_gemm(PDT_GEMM_NN, A, W, C, M, N, K, e, tile);
+  return C;
+}
+// G[M,N] (fp32, += when accumulate) = A[K,M]^T * B[K,N]  -- weight gradients; split-K slabs + reduce
+void gemm_tn_into(const Tensor& A, const Tensor& B, Tensor& G, bool accumulate, int tile = -1, int splits = 0) {
+  chk16(A, "A"); chk16(B, "B"); chkf32(G, "G");
+  const int K = (int)A.size(0), M = (int)A.size(1), N = (int)B.size(1);
+  TORCH_CHECK(B.size(0) == K && G.size(0) == M && G.size(1) == N, "gemm_tn: shape mismatch");
+  Tensor slab = at::empty({(int64_t)pdt_gemm_max_splits() * M * N}, G.options());
+  PdtGemm g{};
+  g.A = A.data_ptr(); g.B = B.data_ptr(); g.C = slab.data_ptr();
+  g.M = M; g.N = N; g.K = K;
+  g.lda = (int)A.stride(0); g.ldb = (int)B.stride(0); g.ldc = N;
+  g.epi = PDT_EPI_SLAB_F32;
+  g.splits = splits;
+  check(pdt_gemm(dt_code(A), PDT_GEMM_TN, tile, &g, cur_stream()), "gemm_tn");
+  check(pdt_splitk_reduce(slab.data_ptr<float>(), g.splits, (int64_t)M * N, G.data_ptr<float>(), accumulate ? 1 : 0,
+                          cur_stream()), "splitk_reduce");
+}
+
+// bias gradient of a 16-bit [rows, ncols] matrix into fp32 out[ncols]
+void colsum_into(const Tensor& X, Tensor& out, bool accumulate) {
+  chk16(X, "X"); chkf32(out, "out");
+  const int rows = (int)X.size(0), ncols = (int)X.size(1);
+  Tensor partial = at::empty({256, ncols}, out.options());
+  int nblk = 0;
+  check(pdt_colsum_partial(dt_code(X), X.data_ptr(), rows, ncols, (int)X.stride(0), partial.data_ptr<float>(), &nblk,
+                           cur_stream()), "colsum_partial");
+  check(pdt_colsum_finish(partial.data_ptr<float>(), nblk, ncols, 1, out.data_ptr<float>(), nullptr, nullptr, nullptr,
+                          accumulate ? 1 : 0, cur_stream()), "colsum_finish");
+}
+
+struct LnBwdOut { Tensor dx, ddrop; };
+// LayerNorm backward + (optional) dropout-masked copy + gamma/beta/bias gradients
+LnBwdOut ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Tensor& gamma, Tensor* g_gamma,
+                Tensor* g_beta, Tensor* g_bias, double drop_p, PdtRng rng, bool accumulate) {
+  const int rows = (int)x.size(0), H = (int)x.size(1);
+  LnBwdOut o;
+  o.dx = at::empty_like(x);
+  const bool masked = drop_p > 0.0;
+  o.ddrop = masked ? at::empty_like(x) : o.dx;
+  Tensor partial = at::empty({(int64_t)pdt_layernorm_bwd_max_blocks() * 3 * H}, stats.options());
+  int nblk = 0;
+  check(pdt_layernorm_bwd(dt_code(x), dy.data_ptr(), x.data_ptr(), stats.data_ptr<float>(), gamma.data_ptr(),
+                          o.dx.data_ptr(), masked ? o.ddrop.data_ptr() : nullptr, partial.data_ptr<float>(), &nblk,
+                          rows, H, keep_scale(drop_p), thr16(drop_p), rng, cur_stream()), "layernorm_bwd");
+  check(pdt_colsum_finish(partial.data_ptr<float>(), nblk, H, 3, g_gamma ? g_gamma->data_ptr<float>() : nullptr,
+                          g_beta ? g_beta->data_ptr<float>() : nullptr, g_bias ? g_bias->data_ptr<float>() : nullptr,
+                          nullptr, accumulate ? 1 : 0, cur_stream()), "colsum_finish");
+  return o;
+}
+
+Tensor ln_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, Tensor& stats, double eps) {
+  Tensor y = at::empty_like(x);
+  check(pdt_layernorm_fwd(dt_code(x), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                          stats.data_ptr<float>(), (int)x.size(0), (int)x.size(1), (float)eps, cur_stream()),
+        "layernorm_fwd");
+  return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Encoder layer.  Weight list order (16-bit compute copies):
+//   0 wqkv[3H,H] 1 bqkv[3H] 2 wo[H,H] 3 bo[H] 4 ln1_g 5 ln1_b 6 w1[F,H] 7 b1[F] 8 w2[H,F] 9 b2[H] 10 ln2_g 11 ln2_b
+// Gradient list: the same order, fp32 views of the gradient arena.
+// Saved list: 0 qkv 1 ctx 2 lse 3 z1 4 stats1 5 x1 6 u 7 gact 8 z2 9 stats2
+// ---------------------------------------------------------------------------------------------------
+struct LayerDims { int B, S, A; double p_attn, p_hidden, eps; int64_t micro, layer; };
+
+std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Tensor& kv_len,
+                                  const std::vector<Tensor>& w, const Tensor& rng_state, int64_t B, int64_t S, int64_t A,
+                                  double p_attn, double p_hidden, double eps, int64_t micro, int64_t layer) {
+  c10::hip::HIPGuard guard(x.device());
+  chk16(x, "x");
+  TORCH_CHECK(w.size() == 12, "layer_forward: 12 weight tensors expected");
+  const int T = (int)x.size(0), H = (int)x.size(1);
+  TORCH_CHECK(T == B * S && H == A * 64, "layer_forward: head_dim must be 64 and x must be [B*S, H]");
+  auto f32 = x.options().dtype(at::kFloat);
+  const int64_t site = layer * 4;
+
+  Epi e_bias; e_bias.kind = PDT_EPI_BIAS; e_bias.bias = &w[1];
+  Tensor qkv = gemm_nt(x, w[0], e_bias);
+
+  Tensor ctx = at::empty({T, H}, x.options());
+  Tensor lse = at::empty({B, A, S}, f32);
+  check(pdt_attn_fwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+                     lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p_attn), thr16(p_attn),
+                     make_rng(rng_state, micro, site + 0), cur_stream()), "attn_fwd");
+
+  Epi e_ao; e_ao.kind = PDT_EPI_BIAS_DROP_RES; e_ao.bias = &w[3]; e_ao.res = &x; e_ao.drop_p = p_hidden;
+  e_ao.rng = make_rng(rng_state, micro, site + 1);
+  Tensor z1 = gemm_nt(ctx, w[2], e_ao);
+  Tensor stats1 = at::empty({T, 2}, f32);
+  Tensor x1 = ln_fwd(z1, w[4], w[5], stats1, eps);
+
+  Tensor u = at::empty({T, (int64_t)w[6].size(0)}, x.options());
+  Epi e_f1; e_f1.kind = PDT_EPI_BIAS_GELU; e_f1.bias = &w[7]; e_f1.aux = &u;
+  Tensor gact = gemm_nt(x1, w[6], e_f1);
+
+  Epi e_f2; e_f2.kind = PDT_EPI_BIAS_DROP_RES; e_f2.bias = &w[9]; e_f2.res = &x1; e_f2.drop_p = p_hidden;
+  e_f2.rng = make_rng(rng_state, micro, site + 2);
+  Tensor z2 = gemm_nt(gact, w[8], e_f2);
+  Tensor stats2 = at::empty({T, 2}, f32);
+  Tensor x2 = ln_fwd(z2, w[10], w[11], stats2, eps);
+  return {x2, qkv, ctx, lse, z1, stats1, x1, u, gact, z2, stats2};
+}
+
+Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Tensor>& sv, const Tensor& mask,
+                      const Tensor& kv_len, const std::vector<Tensor>& w, std::vector<Tensor> gr,
+                      const Tensor& rng_state, int64_t B, int64_t S, int64_t A, double p_attn, double p_hidden,
+                      int64_t micro, int64_t layer, bool accumulate) {
+  c10::hip::HIPGuard guard(x.device());
+  TORCH_CHECK(sv.size() == 10 && w.size() == 12 && gr.size() == 12, "layer_backward: bad list sizes");
+  const Tensor dy = dy_in.contiguous();
+  chk16(dy, "dy");
+  const Tensor &qkv = sv[0], &ctx = sv[1], &lse = sv[2], &z1 = sv[3], &stats1 = sv[4], &x1 = sv[5], &u = sv[6],
+               &gact = sv[7], &z2 = sv[8], &stats2 = sv[9];
+  const int T = (int)x.size(0), H = (int)x.size(1);
+  const int64_t site = layer * 4;
+
+  // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
+  LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2),
+                       accumulate);
+  // FFN2 dgrad fused with GELU' ; wgrad
+  Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
+  Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
+  gemm_tn_into(l2.ddrop, gact, gr[8], accumulate);
+  colsum_into(du, gr[7], accumulate);
+  // FFN1 dgrad + residual gradient ; wgrad
+  Epi e_add; e_add.kind = PDT_EPI_ADD_RES; e_add.res = &l2.dx;
+  Tensor dx1 = gemm_nn(du, w[6], e_add);
+  gemm_tn_into(du, x1, gr[6], accumulate);
+  // LN1
+  LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1),
+                       accumulate);
+  // attention output projection
+  Tensor dctx = gemm_nn(l1.ddrop, w[2], Epi{});
+  gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate);
+  // attention core
+  Tensor dqkv = at::empty_like(qkv);
+  Tensor delta = at::empty_like(lse);
+  check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+                     dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)S,
+                     (int)A, keep_scale(p_attn), thr16(p_attn), make_rng(rng_state, micro, site + 0), cur_stream()),
+        "attn_bwd");
+  colsum_into(dqkv, gr[1], accumulate);
+  // QKV projection dgrad + residual gradient ; wgrad
+  Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
+  Tensor dx = gemm_nn(dqkv, w[0], e_add2);
+  gemm_tn_into(dqkv, x, gr[0], accumulate);
+  (void)T; (void)H;
+  return dx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Embeddings
+// ---------------------------------------------------------------------------------------------------
+std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor& pos_ids, const Tensor& type_ids,
+                                  const c10::optional<Tensor>& inputs_embeds, const Tensor& word, const Tensor& pos,
+                                  const Tensor& type, const Tensor& gamma, const Tensor& beta, const Tensor& rng_state,
+                                  double eps, double p, int64_t micro, int64_t site) {
+  c10::hip::HIPGuard guard(word.device());
+  const int H = (int)word.size(1);
+  const int tokens = (int)pos_ids.numel();
+  Tensor pre = at::empty({tokens, H}, word.options());
+  Tensor y = at::empty({tokens, H}, word.options());
+  Tensor stats = at::empty({tokens, 2}, word.options().dtype(at::kFloat));
+  const int64_t* idp = ids.has_value() ? ids->data_ptr<int64_t>() : nullptr;
+  const void* iep = nullptr;
+  if (inputs_embeds.has_value()) { chk16(*inputs_embeds, "inputs_embeds"); iep = inputs_embeds->data_ptr(); }
+  check(pdt_embed_fwd(dt_code(word), idp, pos_ids.data_ptr<int64_t>(), type_ids.data_ptr<int64_t>(), iep,
+                      word.data_ptr(), pos.data_ptr(), type.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                      pre.data_ptr(), y.data_ptr(), stats.data_ptr<float>(), tokens, H, (float)eps, keep_scale(p),
+                      thr16(p), make_rng(rng_state, micro, site), cur_stream()), "embed_fwd");
+  return {y, pre, stats};
+}
+
+// grads order: 0 word 1 pos 2 type 3 gamma 4 beta (fp32 arena views).  Returns the gradient wrt the summed
+// embedding (needed only when the caller fed inputs_embeds and wants its gradient).
+Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stats, const c10::optional<Tensor>& ids,
+                      const Tensor& pos_ids, const Tensor& type_ids, const Tensor& gamma, std::vector<Tensor> gr,
+                      const Tensor& rng_state, double p, int64_t micro, int64_t site, int64_t pad_id, bool accumulate) {
+  c10::hip::HIPGuard guard(pre.device());
+  TORCH_CHECK(gr.size() == 5, "embed_backward: 5 gradient tensors expected");
+  const Tensor dy = dy_in.contiguous();
+  const int tokens = (int)pre.size(0), H = (int)pre.size(1);
+  Tensor dmask = dy;
+  if (p > 0.0) {
+    dmask = at::empty_like(dy);
+    check(pdt_dropout_apply(dt_code(dy), dy.data_ptr(), dmask.data_ptr(), dy.numel(), keep_scale(p), thr16(p),
+                            make_rng(rng_state, micro, site), cur_stream()), "dropout_apply");
+  }
+  LnBwdOut l = ln_bwd(dmask, pre, stats, gamma, &gr[3], &gr[4], nullptr, 0.0, make_rng(rng_state, micro, site),
+                      accumulate);
+  if (!accumulate) {
+    gr[0].zero_();
+    gr[1].zero_();
+  }
+  check(pdt_embed_scatter(dt_code(pre), l.dx.data_ptr(), ids.has_value() ? ids->data_ptr<int64_t>() : nullptr,
+                          pos_ids.data_ptr<int64_t>(), ids.has_value() ? gr[0].data_ptr<float>() : nullptr,
+                          gr[1].data_ptr<float>(), tokens, H, pad_id, cur_stream()), "embed_scatter");
+  const int R = (int)gr[2].size(0);
+  Tensor partial = at::empty({256, R, H}, stats.options());
+  int nblk = 0;
+  check(pdt_embed_type_partial(dt_code(pre), l.dx.data_ptr(), type_ids.data_ptr<int64_t>(), partial.data_ptr<float>(),
+                               &nblk, tokens, H, R, cur_stream()), "embed_type_partial");
+  float* gt = gr[2].data_ptr<float>();
+  check(pdt_colsum_finish(partial.data_ptr<float>(), nblk, H, R, gt, R > 1 ? gt + H : nullptr,
+                          R > 2 ? gt + 2 * H : nullptr, R > 3 ? gt + 3 * H : nullptr, accumulate ? 1 : 0, cur_stream()),
+        "colsum_finish");
+  return l.dx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pooler (dense + tanh on token 0) and classifier + cross-entropy
+// ---------------------------------------------------------------------------------------------------
+Tensor dense_tanh_forward(const Tensor& first_tok, const Tensor& W, const Tensor& bias) {
+  c10::hip::HIPGuard guard(W.device());
+  Epi e; e.kind = PDT_EPI_BIAS_TANH; e.bias = &bias;
+  return gemm_nt(first_tok, W, e, 0);
+}
+// dfirst = dpre * W ; gW += dpre^T * first ; gb += colsum(dpre)     (dpre = grad wrt the pre-tanh value)
+Tensor dense_backward(const Tensor& dpre, const Tensor& first_tok, const Tensor& W, Tensor gW, Tensor gb, bool accumulate) {
+  c10::hip::HIPGuard guard(W.device());
+  Tensor dfirst = gemm_nn(dpre, W, Epi{}, 0);
+  gemm_tn_into(dpre, first_tok, gW, accumulate, 0);
+  colsum_into(dpre, gb, accumulate);
+  return dfirst;
+}
+
+std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Tensor& bias,
+                                 const c10::optional<Tensor>& labels, const Tensor& rng_state, double p, int64_t micro,
+                                 int64_t site) {
+  c10::hip::HIPGuard guard(pooled.device());
+  chk16(pooled, "pooled"); chkf32(W, "W"); chkf32(bias, "bias");
+  const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
+  TORCH_CHECK(pooled.is_contiguous(), "pooled must be contiguous");
+  auto f32 = W.options();
+  Tensor logits = at::empty({B, C}, f32);
+  Tensor loss = at::zeros({}, f32);
+  check(pdt_head_fwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), bias.data_ptr<float>(),
+                     labels.has_value() ? labels->data_ptr<int64_t>() : nullptr, logits.data_ptr<float>(),
+                     loss.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site),
+                     cur_stream()), "head_fwd");
+  return {logits, loss};
+}
+
+Tensor head_backward(const Tensor& gloss, const Tensor& pooled, const Tensor& W, const Tensor& logits,
+                     const Tensor& labels, Tensor gW, Tensor gb, const Tensor& rng_state, double p, int64_t micro,
+                     int64_t site, bool accumulate, bool tanh_bwd) {
+  c10::hip::HIPGuard guard(pooled.device());
+  const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
+  Tensor gl = gloss.to(at::kFloat).contiguous();
+  Tensor dpooled = at::empty_like(pooled);
+  check(pdt_head_bwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), logits.data_ptr<float>(),
+                     labels.data_ptr<int64_t>(), gl.data_ptr<float>(), dpooled.data_ptr(), gW.data_ptr<float>(),
+                     gb.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site),
+                     accumulate ? 1 : 0, tanh_bwd ? 1 : 0, cur_stream()), "head_bwd");
+  return dpooled;
+}
+
+Tensor dropout16(const Tensor& x, const Tensor& rng_state, double p, int64_t micro, int64_t site) {
+  c10::hip::HIPGuard guard(x.device());
+  Tensor xc = x.contiguous();
+  Tensor y = at::empty_like(xc);
+  check(pdt_dropout_apply(dt_code(xc), xc.data_ptr(), y.data_ptr(), xc.numel(), keep_scale(p), thr16(p),
+                          make_rng(rng_state, micro, site), cur_stream()), "dropout_apply");
+  return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Optimizer
+// ---------------------------------------------------------------------------------------------------
+void adamw_step(Tensor p, Tensor m, Tensor v, const Tensor& g, const c10::optional<Tensor>& p16, const Tensor& lr,
+                const Tensor& step, Tensor scale_state, double beta1, double beta2, double eps, double weight_decay,
+                bool correct_bias, bool check_finite) {
+  c10::hip::HIPGuard guard(p.device());
+  chkf32(p, "p"); chkf32(m, "m"); chkf32(v, "v"); chkf32(g, "g"); chkf32(lr, "lr"); chkf32(scale_state, "scale_state");
+  TORCH_CHECK(step.scalar_type() == at::kInt && step.is_cuda(), "step must be an int32 GPU scalar");
+  TORCH_CHECK(scale_state.numel() >= 4, "scale_state: float[4]");
+  if (check_finite) check(pdt_grad_check(g.data_ptr<float>(), g.numel(), scale_state.data_ptr<float>(), cur_stream()), "grad_check");
+  PdtAdamW a{};
+  a.p = p.data_ptr<float>(); a.m = m.data_ptr<float>(); a.v = v.data_ptr<float>(); a.g = g.data_ptr<float>();
+  int dtype = PDT_F16;
+  if (p16.has_value()) { chk16(*p16, "p16"); a.p16 = p16->data_ptr(); dtype = dt_code(*p16); }
+  a.n = p.numel();
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+  a.correct_bias = correct_bias ? 1 : 0;
+  a.lr = lr.data_ptr<float>(); a.step = step.data_ptr<int32_t>(); a.scale_state = scale_state.data_ptr<float>();
+  check(pdt_adamw_step(dtype, &a, cur_stream()), "adamw_step");
+}
+void grad_check(const Tensor& g, Tensor scale_state) {
+  c10::hip::HIPGuard guard(g.device());
+  chkf32(g, "g");
+  check(pdt_grad_check(g.data_ptr<float>(), g.numel(), scale_state.data_ptr<float>(), cur_stream()), "grad_check");
+}
+void scaler_update(Tensor scale_state, Tensor step, double growth, double backoff, int64_t interval, bool dynamic) {
+  c10::hip::HIPGuard guard(scale_state.device());
+  check(pdt_scaler_update(scale_state.data_ptr<float>(), step.data_ptr<int32_t>(), (float)growth, (float)backoff,
+                          (int)interval, dynamic ? 1 : 0, cur_stream()), "scaler_update");
+}
+void cast_to_16(const Tensor& src, Tensor dst) {
+  c10::hip::HIPGuard guard(src.device());
+  chkf32(src, "src"); chk16(dst, "dst");
+  TORCH_CHECK(src.numel() == dst.numel(), "cast_to_16: size mismatch");
+  check(pdt_cast_f32_to_16(dt_code(dst), src.data_ptr<float>(), dst.data_ptr(), src.numel(), cur_stream()), "cast");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Single-op entry points (unit tests, micro-benchmarks)
+// ---------------------------------------------------------------------------------------------------
+Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int64_t epi,
+               const c10::optional<Tensor>& bias, const c10::optional<Tensor>& res, c10::optional<Tensor> aux,
+               const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site, int64_t tile) {
+  c10::hip::HIPGuard guard(A.device());
+  Epi e; e.kind = (int)epi; e.drop_p = drop_p;
+  if (bias.has_value()) e.bias = &*bias;
+  if (res.has_value()) e.res = &*res;
+  if (aux.has_value()) e.aux = &*aux;
+  if (rng_state.has_value()) e.rng = make_rng(*rng_state, micro, site);
+  if (layout == "nt") return gemm_nt(A, B, e, (int)tile);
+  if (layout == "nn") return gemm_nn(A, B, e, (int)tile);
+  TORCH_CHECK(false, "op_gemm: layout must be nt or nn");
+}
+Tensor op_gemm_tn(const Tensor& A, const Tensor& B, c10::optional<Tensor> into, bool accumulate, int64_t tile, int64_t splits) {
+  c10::hip::HIPGuard guard(A.device());
+  Tensor G = into.has_value() ? *into : at::zeros({A.size(1), B.size(1)}, A.options().dtype(at::kFloat));
+  gemm_tn_into(A, B, G, accumulate, (int)tile, (int)splits);
+  return G;
+}
+std::vector<Tensor> op_layernorm_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
+  c10::hip::HIPGuard guard(x.device());
+  chk16(x, "x");
+  Tensor stats = at::empty({x.size(0), 2}, x.options().dtype(at::kFloat));
+  Tensor y = ln_fwd(x, gamma, beta, stats, eps);
+  return {y, stats};
+}
+std::vector<Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Tensor& gamma,
+                                     const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site) {
+  c10::hip::HIPGuard guard(x.device());
+  const int H = (int)x.size(1);
+  auto f32 = stats.options();
+  Tensor gg = at::zeros({H}, f32), gb = at::zeros({H}, f32), gbias = at::zeros({H}, f32);
+  PdtRng rng{nullptr, 0, 0};
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  LnBwdOut o = ln_bwd(dy.contiguous(), x, stats, gamma, &gg, &gb, &gbias, drop_p, rng, false);
+  return {o.dx, o.ddrop, gg, gb, gbias};
+}
+std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, int64_t B, int64_t S, int64_t A,
+                                const c10::optional<Tensor>& rng_state, double p, int64_t micro, int64_t site) {
+  c10::hip::HIPGuard guard(qkv.device());
+  chk16(qkv, "qkv");
+  TORCH_CHECK(qkv.is_contiguous() && qkv.size(0) == B * S && qkv.size(1) == 3 * A * 64, "qkv must be [B*S, 3*A*64]");
+  Tensor ctx = at::empty({B * S, A * 64}, qkv.options());
+  Tensor lse = at::empty({B, A, S}, qkv.options().dtype(at::kFloat));
+  PdtRng rng{nullptr, 0, 0};
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  check(pdt_attn_fwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+                     lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p), thr16(p), rng, cur_stream()), "attn_fwd");
+  return {ctx, lse};
+}
+Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, const Tensor& ctx, const Tensor& dctx,
+                   const Tensor& lse, int64_t B, int64_t S, int64_t A, const c10::optional<Tensor>& rng_state, double p,
+                   int64_t micro, int64_t site) {
+  c10::hip::HIPGuard guard(qkv.device());
+  Tensor dqkv = at::empty_like(qkv);
+  Tensor delta = at::empty_like(lse);
+  Tensor dc = dctx.contiguous();
+  PdtRng rng{nullptr, 0, 0};
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+                     dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)S,
+                     (int)A, keep_scale(p), thr16(p), rng, cur_stream()), "attn_bwd");
+  return dqkv;
+}
+
+}  // namespace
+
+void bind_reducer(py::module_& m);  // reducer.cpp
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "gfx950 kernels + native runtime of pytorch_distributed_training_amd";
+  m.def("layer_forward", &layer_forward);
+  m.def("layer_backward", &layer_backward);
+  m.def("embed_forward", &embed_forward);
+  m.def("embed_backward", &embed_backward);
+  m.def("dense_tanh_forward", &dense_tanh_forward);
+  m.def("dense_backward", &dense_backward);
+  m.def("head_forward", &head_forward);
+  m.def("head_backward", &head_backward);
+  m.def("dropout16", &dropout16);
+  m.def("adamw_step", &adamw_step);
+  m.def("grad_check", &grad_check);
+  m.def("scaler_update", &scaler_update);
+  m.def("cast_to_16", &cast_to_16);
+  m.def("op_gemm", &op_gemm);
+  m.def("op_gemm_tn", &op_gemm_tn);
+  m.def("op_layernorm_fwd", &op_layernorm_fwd);
+  m.def("op_layernorm_bwd", &op_layernorm_bwd);
+  m.def("op_attn_fwd", &op_attn_fwd);
+  m.def("op_attn_bwd", &op_attn_bwd);
+  bind_reducer(m);
+}

@@ -1,0 +1,176 @@
+// GradBucketReducer: the data-parallel gradient path.
+//
+// What the reference gets from torch's DDP reducer through `accelerator.prepare(model)`
+// (/root/reference/test_data_parallelism.py:125-127) and the explicit
+// `DistributedDataParallel(...)` + `no_sync()` of /root/reference/test_model_parallelism.py:248-253,292-296
+// is rebuilt around one design decision: gradients are born inside a flat fp32 arena, and a bucket is a
+// contiguous slice of that arena (one encoder layer ~ 50 MB for BERT-large, which keeps every one of the 7
+// xGMI links of a GPU bandwidth-bound rather than latency-bound).  So there is no gather-into-bucket copy,
+// no copy-back, and the all-reduce of a bucket is issued the moment the layer's backward has been enqueued:
+// RCCL runs it on its own HIP stream (ordered after the producing kernels by an event) while the compute
+// stream continues with the next layer's backward.
+//
+// The collective backend is a c10d::ProcessGroup: "nccl" (= RCCL over xGMI) on GPUs, "gloo" for the
+// CPU plumbing configuration - the identical C++ code path is exercised by the CPU multi-process tests.
+#include <torch/extension.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <torch/csrc/distributed/c10d/Types.hpp>
+#include <torch/csrc/distributed/c10d/Work.hpp>
+
+#include <chrono>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+using at::Tensor;
+using PG = c10::intrusive_ptr<c10d::ProcessGroup>;
+
+class GradBucketReducer {
+ public:
+  GradBucketReducer(PG pg, Tensor arena, std::vector<int64_t> bounds, std::vector<int64_t> expected, bool average,
+                    int64_t comm_dtype_code)
+      : pg_(std::move(pg)), arena_(std::move(arena)), bounds_(std::move(bounds)), expected_(std::move(expected)),
+        average_(average) {
+    // wire dtype of the all-reduce: 0 = the arena's own (fp32), 1 = float16, 2 = bfloat16
+    if (comm_dtype_code == 1) comm_dtype_ = at::kHalf;
+    if (comm_dtype_code == 2) comm_dtype_ = at::kBFloat16;
+    TORCH_CHECK(arena_.dim() == 1 && arena_.is_contiguous(), "gradient arena must be flat and contiguous");
+    TORCH_CHECK(bounds_.size() >= 2 && bounds_.size() == expected_.size() + 1, "bounds/expected size mismatch");
+    TORCH_CHECK(bounds_.front() == 0 && bounds_.back() <= arena_.numel(), "bucket bounds outside the arena");
+    nb_ = (int)expected_.size();
+    for (int i = 0; i < nb_; ++i) {
+      TORCH_CHECK(bounds_[i] < bounds_[i + 1], "empty bucket ", i);
+      views_.push_back(arena_.narrow(0, bounds_[i], bounds_[i + 1] - bounds_[i]));
+    }
+    world_ = pg_->getSize();
+    is_nccl_ = pg_->getBackendName() == "nccl";
+    reset();
+  }
+
+  // Start a backward pass.  sync=false is the no_sync() mode: gradients only accumulate locally.
+  void begin(bool sync) {
+    reset();
+    sync_ = sync;
+    active_ = true;
+  }
+
+  // `count` producers of bucket `b` have enqueued their gradient kernels.
+  void mark_ready(int64_t b, int64_t count) {
+    if (!active_ || !sync_) return;
+    TORCH_CHECK(b >= 0 && b < nb_, "bucket index out of range");
+    ready_[b] += count;
+    TORCH_CHECK(ready_[b] <= expected_[b], "bucket ", b, " marked ready more often than it has producers");
+    launch_ready_prefix();
+  }
+
+  // End of backward: buckets nobody marked (parameters that took no part in this graph - their arena slice
+  // is still zero) are reduced too, in index order, so every rank issues the same sequence of collectives;
+  // then the compute stream is made to wait for all of them.
+  void finish() {
+    if (!active_) return;
+    active_ = false;
+    if (!sync_) return;
+    for (int b = next_; b < nb_; ++b) launch(b);
+    next_ = nb_;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int b = 0; b < nb_; ++b) {
+      if (!works_[b]) continue;
+      works_[b]->wait();
+      works_[b].reset();
+      if (staged_[b].defined()) {
+        views_[b].copy_(staged_[b]);
+        staged_[b] = Tensor();
+      }
+      if (average_ && !native_avg()) views_[b].div_((double)world_);
+    }
+    wait_us_total_ += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    ++steps_;
+  }
+
+  // rank `root`'s values of `t` (any flat tensor, e.g. the parameter arena) to everyone, in chunks
+  void broadcast(Tensor t, int64_t root, int64_t chunk_elems) {
+    TORCH_CHECK(t.dim() == 1 && t.is_contiguous(), "broadcast expects a flat contiguous tensor");
+    if (world_ == 1) return;
+    std::vector<c10::intrusive_ptr<c10d::Work>> ws;
+    for (int64_t o = 0; o < t.numel(); o += chunk_elems) {
+      std::vector<Tensor> v{t.narrow(0, o, std::min(chunk_elems, t.numel() - o))};
+      c10d::BroadcastOptions opts;
+      opts.rootRank = root;
+      ws.push_back(pg_->broadcast(v, opts));
+    }
+    for (auto& w : ws) w->wait();
+  }
+
+  int64_t num_buckets() const { return nb_; }
+  int64_t world_size() const { return world_; }
+  std::vector<int64_t> launch_order() const { return order_; }
+  py::dict stats() const {
+    py::dict d;
+    d["steps"] = steps_;
+    d["collectives"] = launches_;
+    d["bytes"] = bytes_;
+    d["host_wait_us"] = wait_us_total_;
+    return d;
+  }
+
+ private:
+  bool native_avg() const { return is_nccl_; }
+
+  void reset() {
+    ready_.assign(nb_, 0);
+    works_.assign(nb_, nullptr);
+    staged_.assign(nb_, Tensor());
+    order_.clear();
+    next_ = 0;
+  }
+  void launch_ready_prefix() {
+    while (next_ < nb_ && ready_[next_] >= expected_[next_]) launch(next_++);
+  }
+  void launch(int b) {
+    order_.push_back(b);
+    if (world_ == 1) return;  // nothing to exchange; gradients are already the global ones
+    Tensor buf = views_[b];
+    if (comm_dtype_.has_value() && *comm_dtype_ != buf.scalar_type()) {
+      staged_[b] = buf.to(*comm_dtype_);  // halve the bytes on the wire; accumulation stays fp32 in the arena
+      buf = staged_[b];
+    }
+    c10d::AllreduceOptions opts;
+    opts.reduceOp = (average_ && native_avg()) ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+    std::vector<Tensor> v{buf};
+    works_[b] = pg_->allreduce(v, opts);
+    ++launches_;
+    bytes_ += buf.numel() * buf.element_size();
+  }
+
+  PG pg_;
+  Tensor arena_;
+  std::vector<int64_t> bounds_, expected_;
+  bool average_;
+  c10::optional<at::ScalarType> comm_dtype_;
+  int nb_ = 0, world_ = 1, next_ = 0;
+  bool is_nccl_ = false, sync_ = true, active_ = false;
+  std::vector<Tensor> views_, staged_;
+  std::vector<int64_t> ready_, order_;
+  std::vector<c10::intrusive_ptr<c10d::Work>> works_;
+  int64_t steps_ = 0, launches_ = 0, bytes_ = 0, wait_us_total_ = 0;
+};
+
+}  // namespace
+
+void bind_reducer(py::module_& m) {
+  py::class_<GradBucketReducer>(m, "GradBucketReducer")
+      .def(py::init<PG, at::Tensor, std::vector<int64_t>, std::vector<int64_t>, bool, int64_t>(),
+           py::arg("process_group"), py::arg("arena"), py::arg("bounds"), py::arg("expected"), py::arg("average") = true,
+           py::arg("comm_dtype") = 0)
+      .def("begin", &GradBucketReducer::begin, py::arg("sync") = true)
+      .def("mark_ready", &GradBucketReducer::mark_ready, py::arg("bucket"), py::arg("count") = 1)
+      .def("finish", &GradBucketReducer::finish, py::call_guard<py::gil_scoped_release>())
+      .def("broadcast", &GradBucketReducer::broadcast, py::arg("tensor"), py::arg("root") = 0,
+           py::arg("chunk_elems") = (int64_t)16 << 20, py::call_guard<py::gil_scoped_release>())
+      .def("num_buckets", &GradBucketReducer::num_buckets)
+      .def("world_size", &GradBucketReducer::world_size)
+      .def("launch_order", &GradBucketReducer::launch_order)
+      .def("stats", &GradBucketReducer::stats);
+}

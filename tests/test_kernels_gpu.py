@@ -1,0 +1,340 @@
+"""Numerics of every gfx950 kernel against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def C():
+    from pytorch_distributed_training_amd.ops import native
+
+    return native()
+
+
+def tol(dtype):
+    return (2e-2, 2e-2) if dtype == torch.bfloat16 else (4e-3, 4e-3)
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def rng_state(seed=1234, offset=0):
+    return torch.tensor([seed, offset], dtype=torch.int64, device="cuda")
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 384, 192), (1024, 768, 1024), (77, 128, 128)])
+def test_gemm_nt_plain_and_bias(dtype, tile, M, N, K):
+    torch.manual_seed(0)
+    A = torch.randn(M, K, device="cuda").to(dtype)
+    W = torch.randn(N, K, device="cuda").to(dtype)
+    b = torch.randn(N, device="cuda").to(dtype)
+    out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, tile)
+    ref = A.float() @ W.float().t()
+    assert rel_err(out, ref) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    out = C().op_gemm("nt", A, W, 1, b, None, None, None, 0.0, 0, 0, tile)
+    assert rel_err(out, ref + b.float()) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_asymmetric_identity(dtype):
+    # A = I with an asymmetric B catches a transposed C write
+    n = 256
+    A = torch.eye(n, device="cuda").to(dtype)
+    W = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).float().sub(125).div(16).to(dtype)
+    out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, 1)
+    assert torch.equal(out.float(), W.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1])
+def test_gemm_nt_gelu_and_residual_epilogues(dtype, tile):
+    torch.manual_seed(1)
+    M, N, K = 520, 512, 256
+    A = (torch.randn(M, K, device="cuda") * 0.5).to(dtype)
+    W = (torch.randn(N, K, device="cuda") * 0.1).to(dtype)
+    b = torch.randn(N, device="cuda").to(dtype)
+    res = torch.randn(M, N, device="cuda").to(dtype)
+    u = torch.empty(M, N, device="cuda", dtype=dtype)
+    g = C().op_gemm("nt", A, W, 2, b, None, u, None, 0.0, 0, 0, tile)
+    pre = A.float() @ W.float().t() + b.float()
+    assert rel_err(u, pre) < 1e-2
+    assert rel_err(g, F.gelu(pre)) < 1e-2
+    z = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(), 0.0, 0, 0, tile)
+    assert rel_err(z, pre + res.float()) < 1e-2
+    t = C().op_gemm("nt", A, W, 7, b, None, None, None, 0.0, 0, 0, tile)
+    assert rel_err(t, torch.tanh(pre)) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dropout_epilogue_statistics_and_replay(dtype):
+    M, N, K = 512, 1024, 64
+    A = torch.zeros(M, K, device="cuda", dtype=dtype)
+    W = torch.zeros(N, K, device="cuda", dtype=dtype)
+    b = torch.ones(N, device="cuda", dtype=dtype)
+    res = torch.zeros(M, N, device="cuda", dtype=dtype)
+    st = rng_state(7, 3)
+    z1 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 2, 5, 1)
+    z2 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 2, 5, 0)  # other tile shape: same mask
+    assert torch.equal(z1, z2)
+    keep = (z1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    assert abs(z1.float().max().item() - 1 / 0.9) < 2e-2
+    z3 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 3, 5, 1)  # other micro-batch: other mask
+    assert not torch.equal(z1, z3)
+    # the standalone dropout kernel regenerates the same mask (what LN backward relies on)
+    ones = torch.ones(M, N, device="cuda", dtype=dtype)
+    d = C().dropout16(ones, st, 0.1, 2, 5)
+    assert torch.equal(d != 0, z1 != 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (333, 512, 768), (1024, 1024, 3072)])
+def test_gemm_nn_dgrad(dtype, tile, M, N, K):
+    torch.manual_seed(2)
+    dY = (torch.randn(M, K, device="cuda") * 0.5).to(dtype)
+    W = (torch.randn(K, N, device="cuda") * 0.1).to(dtype)  # [out=K, in=N]
+    out = C().op_gemm("nn", dY, W, 0, None, None, None, None, 0.0, 0, 0, tile)
+    ref = dY.float() @ W.float()
+    assert rel_err(out, ref) < 1e-2
+    res = torch.randn(M, N, device="cuda").to(dtype)
+    out = C().op_gemm("nn", dY, W, 5, None, res, None, None, 0.0, 0, 0, tile)
+    assert rel_err(out, ref + res.float()) < 1e-2
+    u = torch.randn(M, N, device="cuda").to(dtype)
+    out = C().op_gemm("nn", dY, W, 4, None, None, u, None, 0.0, 0, 0, tile)
+    uf = u.float().requires_grad_()
+    F.gelu(uf).backward(ref)
+    assert rel_err(out, uf.grad) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nn_asymmetric_identity(dtype):
+    n = 256
+    A = torch.eye(n, device="cuda").to(dtype)
+    W = (torch.arange(n * n, device="cuda").reshape(n, n) % 241).float().sub(120).div(16).to(dtype)
+    out = C().op_gemm("nn", A, W, 0, None, None, None, None, 0.0, 0, 0, 1)
+    assert torch.equal(out.float(), W.float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("T,M,N", [(64, 256, 256), (1000, 512, 256), (4096, 768, 3072), (130, 128, 384)])
+def test_gemm_tn_wgrad(dtype, tile, T, M, N):
+    torch.manual_seed(3)
+    dY = (torch.randn(T, M, device="cuda") * 0.5).to(dtype)
+    X = (torch.randn(T, N, device="cuda") * 0.5).to(dtype)
+    G = C().op_gemm_tn(dY, X, None, False, tile, 0)
+    ref = dY.float().t() @ X.float()
+    assert rel_err(G, ref) < 5e-3
+    G2 = C().op_gemm_tn(dY, X, G.clone(), True, tile, 3)
+    assert rel_err(G2, 2 * ref) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,H", [(37, 128), (512, 768), (1000, 1024)])
+def test_layernorm_fwd_bwd(dtype, rows, H):
+    torch.manual_seed(4)
+    x = torch.randn(rows, H, device="cuda").to(dtype)
+    g = (1 + 0.1 * torch.randn(H, device="cuda")).to(dtype)
+    b = (0.1 * torch.randn(H, device="cuda")).to(dtype)
+    y, stats = C().op_layernorm_fwd(x, g, b, 1e-12)
+    xf = x.float().requires_grad_()
+    gf, bf = g.float().requires_grad_(), b.float().requires_grad_()
+    ref = F.layer_norm(xf, (H,), gf, bf, 1e-12)
+    rt, at = tol(dtype)
+    torch.testing.assert_close(y.float(), ref, rtol=rt, atol=at)
+    dy = torch.randn(rows, H, device="cuda").to(dtype)
+    ref.backward(dy.float())
+    dx, ddrop, gg, gb, gbias = C().op_layernorm_bwd(dy, x, stats, g, None, 0.0, 0, 0)
+    assert rel_err(dx, xf.grad) < 2e-2
+    assert rel_err(gg, gf.grad) < 1e-2
+    assert rel_err(gb, bf.grad) < 1e-2
+    assert rel_err(gbias, dx.float().sum(0)) < 1e-2
+    # with dropout: ddrop = mask * dx / keep, and the bias gradient sums ddrop
+    st = rng_state(5, 1)
+    dx2, ddrop2, _, _, gbias2 = C().op_layernorm_bwd(dy, x, stats, g, st, 0.25, 1, 9)
+    mask = C().dropout16(torch.ones_like(x), st, 0.25, 1, 9)
+    assert torch.equal(dx2, dx)
+    torch.testing.assert_close(ddrop2.float(), dx.float() * mask.float(), rtol=1e-2, atol=1e-3)
+    assert rel_err(gbias2, ddrop2.float().sum(0)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ attention
+def ref_attention(qkv, mask, B, S, A, probs_mask=None, keep=1.0):
+    H = A * 64
+    q, k, v = qkv.float().view(B, S, 3, A, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / 8.0
+    s = s + (1.0 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+    p = torch.softmax(s, -1)
+    if probs_mask is not None:
+        p = p * probs_mask / keep
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * S, H), p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,A", [(2, 128, 2), (3, 77, 4), (2, 200, 2), (1, 512, 2), (2, 384, 1)])
+def test_attention_fwd_bwd(dtype, B, S, A):
+    torch.manual_seed(5)
+    H = A * 64
+    qkv = (torch.randn(B * S, 3 * H, device="cuda") * 0.7).to(dtype)
+    lens = torch.randint(max(1, S // 3), S + 1, (B,), device="cuda")
+    lens[0] = S
+    mask = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).to(torch.int32)
+    kv_len = lens.to(torch.int32)
+    ctx, lse = C().op_attn_fwd(qkv, mask, kv_len, B, S, A, None, 0.0, 0, 0)
+    qf = qkv.float().requires_grad_()
+    ref, _ = ref_attention(qf, mask, B, S, A)
+    rt, at = tol(dtype)
+    torch.testing.assert_close(ctx.float(), ref, rtol=rt, atol=at)
+    dctx = torch.randn(B * S, H, device="cuda").to(dtype)
+    # padded query rows carry no gradient in a real model
+    dctx = dctx * mask.view(B * S, 1).to(dtype)
+    ref.backward(dctx.float())
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, None, 0.0, 0, 0)
+    assert rel_err(dqkv, qf.grad) < (3e-2 if dtype == torch.bfloat16 else 6e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_general_mask_and_dropout(dtype):
+    torch.manual_seed(6)
+    B, S, A = 2, 128, 2
+    H = A * 64
+    qkv = (torch.randn(B * S, 3 * H, device="cuda") * 0.5).to(dtype)
+    mask = (torch.rand(B, S, device="cuda") > 0.3).to(torch.int32)
+    mask[:, 0] = 1
+    idx = torch.arange(1, S + 1, device="cuda", dtype=torch.int32)
+    kv_len = (mask * idx).amax(1).to(torch.int32)
+    st = rng_state(11, 2)
+    p = 0.1
+    # recover the probability mask from V = identity-like probes: run with V = one-hot over keys in chunks of 64
+    ctx, lse = C().op_attn_fwd(qkv, mask, kv_len, B, S, A, st, p, 1, 4)
+    ctx0, _ = C().op_attn_fwd(qkv, mask, kv_len, B, S, A, None, 0.0, 0, 0)
+    probes = []
+    for c in range(S // 64):
+        q2 = qkv.clone().view(B, S, 3, A, 64)
+        eye = torch.zeros(S, 64, device="cuda", dtype=dtype)
+        eye[c * 64:(c + 1) * 64] = torch.eye(64, device="cuda", dtype=dtype)
+        q2[:, :, 2] = eye[None, :, None, :]
+        o, _ = C().op_attn_fwd(q2.view(B * S, 3 * H), mask, kv_len, B, S, A, st, p, 1, 4)
+        probes.append(o.view(B, S, A, 64))
+    pd = torch.cat(probes, -1).permute(0, 2, 1, 3).float()  # [B,A,S(q),S(k)] dropped probabilities
+    _, pref = ref_attention(qkv, mask, B, S, A)
+    keepmask = (pd != 0).float()
+    valid = pref > 1e-4
+    frac = keepmask[valid].mean().item()
+    assert abs(frac - (1 - p)) < 0.02
+    torch.testing.assert_close(pd, pref * keepmask / (1 - p), rtol=3e-2, atol=3e-3)
+    # backward with the same dropout mask
+    qf = qkv.float().requires_grad_()
+    ref, _ = ref_attention(qf, mask, B, S, A, keepmask, 1 - p)
+    torch.testing.assert_close(ctx.float(), ref, rtol=3e-2, atol=2e-2)
+    dctx = torch.randn(B * S, H, device="cuda").to(dtype)
+    ref.backward(dctx.float())
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, st, p, 1, 4)
+    # keys that are masked get exactly zero gradient
+    gk = dqkv.view(B, S, 3, A, 64)[:, :, 1:]
+    assert gk[mask == 0].abs().max().item() == 0
+    assert rel_err(dqkv, qf.grad) < (4e-2 if dtype == torch.bfloat16 else 1e-2)
+    assert ctx0.shape == ctx.shape
+
+
+# ------------------------------------------------------------------------------------------ embeddings / head / optimizer
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embeddings_fwd_bwd(dtype):
+    torch.manual_seed(7)
+    V, P, R, H, B, S = 300, 64, 2, 128, 3, 40
+    word = (torch.randn(V, H, device="cuda") * 0.5).to(dtype)
+    pos = (torch.randn(P, H, device="cuda") * 0.5).to(dtype)
+    typ = (torch.randn(R, H, device="cuda") * 0.5).to(dtype)
+    g = (1 + 0.1 * torch.randn(H, device="cuda")).to(dtype)
+    b = (0.1 * torch.randn(H, device="cuda")).to(dtype)
+    ids = torch.randint(0, V, (B * S,), device="cuda")
+    ids[:5] = 0  # padding rows
+    pids = torch.arange(S, device="cuda").repeat(B)
+    tids = torch.randint(0, R, (B * S,), device="cuda")
+    st = rng_state()
+    y, pre, stats = C().embed_forward(ids, pids, tids, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+    wf, pf, tf = word.float().requires_grad_(), pos.float().requires_grad_(), typ.float().requires_grad_()
+    gf, bf = g.float().requires_grad_(), b.float().requires_grad_()
+    e = F.embedding(ids, wf, padding_idx=0) + F.embedding(pids, pf) + F.embedding(tids, tf)
+    ref = F.layer_norm(e, (H,), gf, bf, 1e-12)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    dy = torch.randn(B * S, H, device="cuda").to(dtype)
+    ref.backward(dy.float())
+    f32 = dict(device="cuda", dtype=torch.float32)
+    grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
+             torch.zeros(H, **f32)]
+    C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, False)
+    for got, want in zip(grads, [wf.grad, pf.grad, tf.grad, gf.grad, bf.grad]):
+        assert rel_err(got, want) < 2e-2
+    assert grads[0][0].abs().max().item() == 0  # padding row
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_fwd_bwd(dtype):
+    torch.manual_seed(8)
+    B, H, Cn = 37, 256, 2
+    pooled = torch.tanh(torch.randn(B, H, device="cuda")).to(dtype)
+    W = torch.randn(Cn, H, device="cuda") * 0.1
+    bias = torch.randn(Cn, device="cuda") * 0.1
+    labels = torch.randint(0, Cn, (B,), device="cuda")
+    st = rng_state()
+    logits, loss = C().head_forward(pooled, W, bias, labels, st, 0.0, 0, 0)
+    pf = pooled.float().requires_grad_()
+    Wf, bf = W.clone().requires_grad_(), bias.clone().requires_grad_()
+    rl = F.linear(pf, Wf, bf)
+    rloss = F.cross_entropy(rl, labels)
+    torch.testing.assert_close(logits, rl, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(loss, rloss, rtol=1e-5, atol=1e-5)
+    (rloss * 3.0).backward()
+    gW, gb = torch.zeros_like(W), torch.zeros_like(bias)
+    dp = C().head_backward(torch.tensor(3.0, device="cuda"), pooled, W, logits, labels, gW, gb, st, 0.0, 0, 0, False, False)
+    assert rel_err(dp, pf.grad) < 1e-2
+    assert rel_err(gW, Wf.grad) < 1e-4
+    assert rel_err(gb, bf.grad) < 1e-4
+
+
+def test_adamw_matches_hf_formula_and_skips_on_overflow():
+    torch.manual_seed(9)
+    n = 4096 + 64
+    p0 = torch.randn(n, device="cuda")
+    g = torch.randn(n, device="cuda")
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, device="cuda", dtype=torch.float16)
+    lr = torch.tensor([1e-3], device="cuda")
+    step = torch.zeros(1, device="cuda", dtype=torch.int32)
+    scale = 128.0
+    state = torch.tensor([scale, 0.0, 0.0, 0.0], device="cuda")
+    rp, rm, rv = p0.clone().double(), torch.zeros(n, device="cuda").double(), torch.zeros(n, device="cuda").double()
+    b1, b2, eps, wd = 0.9, 0.999, 1e-6, 0.01
+    for t in range(1, 4):
+        C().adamw_step(p, m, v, g * scale, p16, lr, step, state, b1, b2, eps, wd, True, True)
+        C().scaler_update(state, step, 2.0, 0.5, 2000, True)
+        gd = g.double()
+        rm = b1 * rm + (1 - b1) * gd
+        rv = b2 * rv + (1 - b2) * gd * gd
+        ss = 1e-3 * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        rp = rp - ss * rm / (rv.sqrt() + eps)
+        rp = rp - 1e-3 * wd * rp
+    torch.testing.assert_close(p.double(), rp, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p16.float(), p, rtol=1e-3, atol=1e-3)
+    assert step.item() == 3 and state[1].item() == 3
+    # overflow: nothing moves, scale halves, step does not advance
+    before = p.clone()
+    gbad = g * scale
+    gbad[17] = float("inf")
+    C().adamw_step(p, m, v, gbad, p16, lr, step, state, b1, b2, eps, wd, True, True)
+    C().scaler_update(state, step, 2.0, 0.5, 2000, True)
+    assert torch.equal(p, before)
+    assert state[0].item() == scale / 2 and step.item() == 3 and state[3].item() == 1.0
