@@ -86,7 +86,9 @@ def build(jobs: int = 8, verbose: bool = False, force: bool = False) -> str:
     for s in cpp:
         obj = os.path.join(BUILD, os.path.basename(s) + ".o")
         cmd = [hipcc] + host_flags + ["-c", s, "-o", obj]
-        tasks.append((s, obj, cmd, _stamp([s] + hdr, host_flags)))
+        # the host runtime only sees the plain-C launch interface of the kernels, not their device headers
+        host_hdr = [h for h in hdr if h.endswith("api.h") or os.sep + "runtime" + os.sep in h]
+        tasks.append((s, obj, cmd, _stamp([s] + host_hdr, host_flags)))
     if force:
         for _, obj, _, _ in tasks:
             if os.path.exists(obj + ".stamp"):

@@ -102,10 +102,12 @@ int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t*
 int pdt_head_fwd(int dtype, const void* pooled, const float* W, const float* bias, const int64_t* labels,
                  float* logits, float* loss, int B, int H, int C, float drop_scale, uint32_t drop_thr, PdtRng rng,
                  void* stream);
-// gloss[0] = upstream gradient of the mean loss.  dpooled 16-bit [B,H] (times 1-pooled^2 when tanh_bwd);
+// gloss[0] = upstream gradient of the mean loss (null: no CE term); dlogits_in [B,C] = explicit upstream
+// gradient of the logits (null: none).  dpooled 16-bit [B,H] (times 1-pooled^2 when tanh_bwd);
 // dW [C,H], dbias [C] fp32 (+= when accumulate)
 int pdt_head_bwd(int dtype, const void* pooled, const float* W, const float* logits, const int64_t* labels,
-                 const float* gloss, void* dpooled, float* dW, float* dbias, int B, int H, int C, float drop_scale,
+                 const float* gloss, const float* dlogits_in, void* dpooled, float* dW, float* dbias, int B, int H,
+                 int C, float drop_scale,
                  uint32_t drop_thr, PdtRng rng, int accumulate, int tanh_bwd, void* stream);
 
 // ---- Optimizer ----------------------------------------------------------------------------------------

@@ -94,7 +94,9 @@ struct DropKey {
   uint32_t stream, micro;
 };
 __device__ __forceinline__ DropKey drop_key(const RngArgs& r) {
-  uint64_t seed = r.state[0], off = r.state[1];
+  // a null state means "no dropout at this call site": never dereference it
+  uint64_t seed = 0, off = 0;
+  if (r.state) { seed = r.state[0]; off = r.state[1]; }
   uint64_t mixed = seed ^ (off * 0x9E3779B97F4A7C15ull);
   DropKey k;
   k.key = make_uint2((uint32_t)mixed, (uint32_t)(mixed >> 32));

@@ -66,20 +66,27 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ poo
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ pooled, const float* __restrict__ W,
                                                        const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                       const float* __restrict__ gloss, T* __restrict__ dpooled,
+                                                       const float* __restrict__ gloss,
+                                                       const float* __restrict__ dlogits_in, T* __restrict__ dpooled,
                                                        float* __restrict__ dW, float* __restrict__ dbias, int B, int H, int C,
                                                        float drop_scale, uint32_t drop_thr, RngArgs rng, int accumulate,
                                                        int tanh_bwd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* dl = reinterpret_cast<float*>(smem);  // [B][C]
-  const float gl = gloss[0] / B;
+  // gradient wrt the logits = built-in mean-CE term (when labels and gloss are given) + an explicit
+  // upstream gradient (when the caller computed its own loss from the logits)
+  const bool ce = labels != nullptr && gloss != nullptr;
+  const float gl = ce ? gloss[0] / B : 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     float mx = -INFINITY, se = 0.f;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)b * C + c]);
     for (int c = 0; c < C; ++c) se += __expf(logits[(size_t)b * C + c] - mx);
-    const int y = (int)labels[b];
-    for (int c = 0; c < C; ++c)
-      dl[b * C + c] = (__expf(logits[(size_t)b * C + c] - mx) / se - (c == y ? 1.f : 0.f)) * gl;
+    const int y = ce ? (int)labels[b] : -1;
+    for (int c = 0; c < C; ++c) {
+      float d = ce ? (__expf(logits[(size_t)b * C + c] - mx) / se - (c == y ? 1.f : 0.f)) * gl : 0.f;
+      if (dlogits_in) d += dlogits_in[(size_t)b * C + c];
+      dl[b * C + c] = d;
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x < C) {
@@ -130,13 +137,14 @@ extern "C" int pdt_head_fwd(int dtype, const void* pooled, const float* W, const
 }
 
 extern "C" int pdt_head_bwd(int dtype, const void* pooled, const float* W, const float* logits, const int64_t* labels,
-                            const float* gloss, void* dpooled, float* dW, float* dbias, int B, int H, int C,
+                            const float* gloss, const float* dlogits_in, void* dpooled, float* dW, float* dbias, int B,
+                            int H, int C,
                             float drop_scale, uint32_t drop_thr, PdtRng rng, int accumulate, int tanh_bwd, void* stream) {
   if (C < 1 || C > HEAD_MAX_C || B <= 0 || (size_t)B * C * 4 > 60000) return -3;
   const size_t lds = (size_t)B * C * sizeof(float);
 #define PDT_GO(TT)                                                                                                  \
   hipLaunchKernelGGL(head_bwd_kernel<TT>, dim3((H + 255) / 256), dim3(256), lds, (hipStream_t)stream,               \
-                     (const TT*)pooled, W, logits, labels, gloss, (TT*)dpooled, dW, dbias, B, H, C, drop_scale,     \
+                     (const TT*)pooled, W, logits, labels, gloss, dlogits_in, (TT*)dpooled, dW, dbias, B, H, C, drop_scale,     \
                      drop_thr, rng, accumulate, tanh_bwd)
   if (dtype == PDT_F16) PDT_GO(_Float16); else PDT_GO(__bf16);
 #undef PDT_GO

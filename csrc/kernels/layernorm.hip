@@ -222,6 +222,12 @@ extern "C" int pdt_layernorm_bwd(int dtype, const void* dy, const void* x, const
   nb = nb < 1 ? 1 : (nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   *nblk = nb;
   const size_t lds = (size_t)4 * 3 * H * sizeof(float);
+  if (lds > 65536) {  // H > 1365 needs the opt-in LDS size
+    hipError_t e = dtype == PDT_F16
+                       ? hipFuncSetAttribute((const void*)ln_bwd_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipFuncSetAttribute((const void*)ln_bwd_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   if (dtype == PDT_F16)
     hipLaunchKernelGGL(ln_bwd_kernel<_Float16>, dim3(nb), dim3(256), lds, (hipStream_t)stream, (const _Float16*)dy,
                        (const _Float16*)x, stats, (const _Float16*)gamma, (_Float16*)dx, (_Float16*)ddrop, partial, rows,

@@ -2,8 +2,8 @@
 // encoder-layer forward/backward that chains the kernels (the per-layer "schedule" lives here in C++,
 // so one Python call issues all launches of a layer on the current HIP stream).
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cmath>
 #include <vector>
@@ -15,7 +15,9 @@ using at::Tensor;
 
 namespace {
 
-void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// PyTorch-ROCm names its device type "cuda"; these are the guard / stream classes that accept it.
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 int dt_code(const Tensor& t) {
   if (t.scalar_type() == at::kHalf) return PDT_F16;
@@ -157,7 +159,7 @@ struct LayerDims { int B, S, A; double p_attn, p_hidden, eps; int64_t micro, lay
 std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Tensor& kv_len,
                                   const std::vector<Tensor>& w, const Tensor& rng_state, int64_t B, int64_t S, int64_t A,
                                   double p_attn, double p_hidden, double eps, int64_t micro, int64_t layer) {
-  c10::hip::HIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   chk16(x, "x");
   TORCH_CHECK(w.size() == 12, "layer_forward: 12 weight tensors expected");
   const int T = (int)x.size(0), H = (int)x.size(1);
@@ -196,7 +198,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
                       const Tensor& kv_len, const std::vector<Tensor>& w, std::vector<Tensor> gr,
                       const Tensor& rng_state, int64_t B, int64_t S, int64_t A, double p_attn, double p_hidden,
                       int64_t micro, int64_t layer, bool accumulate) {
-  c10::hip::HIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   TORCH_CHECK(sv.size() == 10 && w.size() == 12 && gr.size() == 12, "layer_backward: bad list sizes");
   const Tensor dy = dy_in.contiguous();
   chk16(dy, "dy");
@@ -246,7 +248,7 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
                                   const c10::optional<Tensor>& inputs_embeds, const Tensor& word, const Tensor& pos,
                                   const Tensor& type, const Tensor& gamma, const Tensor& beta, const Tensor& rng_state,
                                   double eps, double p, int64_t micro, int64_t site) {
-  c10::hip::HIPGuard guard(word.device());
+  DeviceGuard guard(word.device());
   const int H = (int)word.size(1);
   const int tokens = (int)pos_ids.numel();
   Tensor pre = at::empty({tokens, H}, word.options());
@@ -267,7 +269,7 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
 Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stats, const c10::optional<Tensor>& ids,
                       const Tensor& pos_ids, const Tensor& type_ids, const Tensor& gamma, std::vector<Tensor> gr,
                       const Tensor& rng_state, double p, int64_t micro, int64_t site, int64_t pad_id, bool accumulate) {
-  c10::hip::HIPGuard guard(pre.device());
+  DeviceGuard guard(pre.device());
   TORCH_CHECK(gr.size() == 5, "embed_backward: 5 gradient tensors expected");
   const Tensor dy = dy_in.contiguous();
   const int tokens = (int)pre.size(0), H = (int)pre.size(1);
@@ -302,13 +304,13 @@ Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stat
 // Pooler (dense + tanh on token 0) and classifier + cross-entropy
 // ---------------------------------------------------------------------------------------------------
 Tensor dense_tanh_forward(const Tensor& first_tok, const Tensor& W, const Tensor& bias) {
-  c10::hip::HIPGuard guard(W.device());
+  DeviceGuard guard(W.device());
   Epi e; e.kind = PDT_EPI_BIAS_TANH; e.bias = &bias;
   return gemm_nt(first_tok, W, e, 0);
 }
 // dfirst = dpre * W ; gW += dpre^T * first ; gb += colsum(dpre)     (dpre = grad wrt the pre-tanh value)
 Tensor dense_backward(const Tensor& dpre, const Tensor& first_tok, const Tensor& W, Tensor gW, Tensor gb, bool accumulate) {
-  c10::hip::HIPGuard guard(W.device());
+  DeviceGuard guard(W.device());
   Tensor dfirst = gemm_nn(dpre, W, Epi{}, 0);
   gemm_tn_into(dpre, first_tok, gW, accumulate, 0);
   colsum_into(dpre, gb, accumulate);
@@ -318,7 +320,7 @@ Tensor dense_backward(const Tensor& dpre, const Tensor& first_tok, const Tensor&
 std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Tensor& bias,
                                  const c10::optional<Tensor>& labels, const Tensor& rng_state, double p, int64_t micro,
                                  int64_t site) {
-  c10::hip::HIPGuard guard(pooled.device());
+  DeviceGuard guard(pooled.device());
   chk16(pooled, "pooled"); chkf32(W, "W"); chkf32(bias, "bias");
   const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
   TORCH_CHECK(pooled.is_contiguous(), "pooled must be contiguous");
@@ -332,22 +334,26 @@ std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Te
   return {logits, loss};
 }
 
-Tensor head_backward(const Tensor& gloss, const Tensor& pooled, const Tensor& W, const Tensor& logits,
-                     const Tensor& labels, Tensor gW, Tensor gb, const Tensor& rng_state, double p, int64_t micro,
-                     int64_t site, bool accumulate, bool tanh_bwd) {
-  c10::hip::HIPGuard guard(pooled.device());
+Tensor head_backward(const c10::optional<Tensor>& gloss, const c10::optional<Tensor>& dlogits, const Tensor& pooled,
+                     const Tensor& W, const Tensor& logits, const c10::optional<Tensor>& labels, Tensor gW, Tensor gb,
+                     const Tensor& rng_state, double p, int64_t micro, int64_t site, bool accumulate, bool tanh_bwd) {
+  DeviceGuard guard(pooled.device());
   const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
-  Tensor gl = gloss.to(at::kFloat).contiguous();
+  Tensor gl, dl;
+  const bool ce = gloss.has_value() && labels.has_value();
+  if (ce) gl = gloss->to(at::kFloat).contiguous();
+  if (dlogits.has_value()) dl = dlogits->to(at::kFloat).contiguous();
   Tensor dpooled = at::empty_like(pooled);
   check(pdt_head_bwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), logits.data_ptr<float>(),
-                     labels.data_ptr<int64_t>(), gl.data_ptr<float>(), dpooled.data_ptr(), gW.data_ptr<float>(),
+                     ce ? labels->data_ptr<int64_t>() : nullptr, ce ? gl.data_ptr<float>() : nullptr,
+                     dl.defined() ? dl.data_ptr<float>() : nullptr, dpooled.data_ptr(), gW.data_ptr<float>(),
                      gb.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site),
                      accumulate ? 1 : 0, tanh_bwd ? 1 : 0, cur_stream()), "head_bwd");
   return dpooled;
 }
 
 Tensor dropout16(const Tensor& x, const Tensor& rng_state, double p, int64_t micro, int64_t site) {
-  c10::hip::HIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   Tensor xc = x.contiguous();
   Tensor y = at::empty_like(xc);
   check(pdt_dropout_apply(dt_code(xc), xc.data_ptr(), y.data_ptr(), xc.numel(), keep_scale(p), thr16(p),
@@ -361,7 +367,7 @@ Tensor dropout16(const Tensor& x, const Tensor& rng_state, double p, int64_t mic
 void adamw_step(Tensor p, Tensor m, Tensor v, const Tensor& g, const c10::optional<Tensor>& p16, const Tensor& lr,
                 const Tensor& step, Tensor scale_state, double beta1, double beta2, double eps, double weight_decay,
                 bool correct_bias, bool check_finite) {
-  c10::hip::HIPGuard guard(p.device());
+  DeviceGuard guard(p.device());
   chkf32(p, "p"); chkf32(m, "m"); chkf32(v, "v"); chkf32(g, "g"); chkf32(lr, "lr"); chkf32(scale_state, "scale_state");
   TORCH_CHECK(step.scalar_type() == at::kInt && step.is_cuda(), "step must be an int32 GPU scalar");
   TORCH_CHECK(scale_state.numel() >= 4, "scale_state: float[4]");
@@ -377,17 +383,17 @@ void adamw_step(Tensor p, Tensor m, Tensor v, const Tensor& g, const c10::option
   check(pdt_adamw_step(dtype, &a, cur_stream()), "adamw_step");
 }
 void grad_check(const Tensor& g, Tensor scale_state) {
-  c10::hip::HIPGuard guard(g.device());
+  DeviceGuard guard(g.device());
   chkf32(g, "g");
   check(pdt_grad_check(g.data_ptr<float>(), g.numel(), scale_state.data_ptr<float>(), cur_stream()), "grad_check");
 }
 void scaler_update(Tensor scale_state, Tensor step, double growth, double backoff, int64_t interval, bool dynamic) {
-  c10::hip::HIPGuard guard(scale_state.device());
+  DeviceGuard guard(scale_state.device());
   check(pdt_scaler_update(scale_state.data_ptr<float>(), step.data_ptr<int32_t>(), (float)growth, (float)backoff,
                           (int)interval, dynamic ? 1 : 0, cur_stream()), "scaler_update");
 }
 void cast_to_16(const Tensor& src, Tensor dst) {
-  c10::hip::HIPGuard guard(src.device());
+  DeviceGuard guard(src.device());
   chkf32(src, "src"); chk16(dst, "dst");
   TORCH_CHECK(src.numel() == dst.numel(), "cast_to_16: size mismatch");
   check(pdt_cast_f32_to_16(dt_code(dst), src.data_ptr<float>(), dst.data_ptr(), src.numel(), cur_stream()), "cast");
@@ -399,7 +405,7 @@ void cast_to_16(const Tensor& src, Tensor dst) {
 Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int64_t epi,
                const c10::optional<Tensor>& bias, const c10::optional<Tensor>& res, c10::optional<Tensor> aux,
                const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site, int64_t tile) {
-  c10::hip::HIPGuard guard(A.device());
+  DeviceGuard guard(A.device());
   Epi e; e.kind = (int)epi; e.drop_p = drop_p;
   if (bias.has_value()) e.bias = &*bias;
   if (res.has_value()) e.res = &*res;
@@ -410,13 +416,13 @@ Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int6
   TORCH_CHECK(false, "op_gemm: layout must be nt or nn");
 }
 Tensor op_gemm_tn(const Tensor& A, const Tensor& B, c10::optional<Tensor> into, bool accumulate, int64_t tile, int64_t splits) {
-  c10::hip::HIPGuard guard(A.device());
+  DeviceGuard guard(A.device());
   Tensor G = into.has_value() ? *into : at::zeros({A.size(1), B.size(1)}, A.options().dtype(at::kFloat));
   gemm_tn_into(A, B, G, accumulate, (int)tile, (int)splits);
   return G;
 }
 std::vector<Tensor> op_layernorm_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
-  c10::hip::HIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   chk16(x, "x");
   Tensor stats = at::empty({x.size(0), 2}, x.options().dtype(at::kFloat));
   Tensor y = ln_fwd(x, gamma, beta, stats, eps);
@@ -424,7 +430,7 @@ std::vector<Tensor> op_layernorm_fwd(const Tensor& x, const Tensor& gamma, const
 }
 std::vector<Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Tensor& gamma,
                                      const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site) {
-  c10::hip::HIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   const int H = (int)x.size(1);
   auto f32 = stats.options();
   Tensor gg = at::zeros({H}, f32), gb = at::zeros({H}, f32), gbias = at::zeros({H}, f32);
@@ -435,7 +441,7 @@ std::vector<Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& x, const Te
 }
 std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, int64_t B, int64_t S, int64_t A,
                                 const c10::optional<Tensor>& rng_state, double p, int64_t micro, int64_t site) {
-  c10::hip::HIPGuard guard(qkv.device());
+  DeviceGuard guard(qkv.device());
   chk16(qkv, "qkv");
   TORCH_CHECK(qkv.is_contiguous() && qkv.size(0) == B * S && qkv.size(1) == 3 * A * 64, "qkv must be [B*S, 3*A*64]");
   Tensor ctx = at::empty({B * S, A * 64}, qkv.options());
@@ -449,7 +455,7 @@ std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Ten
 Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, const Tensor& ctx, const Tensor& dctx,
                    const Tensor& lse, int64_t B, int64_t S, int64_t A, const c10::optional<Tensor>& rng_state, double p,
                    int64_t micro, int64_t site) {
-  c10::hip::HIPGuard guard(qkv.device());
+  DeviceGuard guard(qkv.device());
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
   Tensor dc = dctx.contiguous();

@@ -270,12 +270,15 @@ class BertPooler(nn.Module):
     def __init__(self, cfg: EncoderConfig):
         super().__init__()
         self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self._native = None
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         first = hidden_states[:, 0]
-        if first.is_cuda and first.dtype in (torch.float16, torch.bfloat16):
-            return torch.tanh(F.linear(first.float(), self.dense.weight, self.dense.bias))
-        return torch.tanh(self.dense(first))
+        if self._native is not None and first.is_cuda:
+            from ..ops import fused
+
+            return fused.dense_tanh(first.to(self._native.w.dtype), self._native)
+        return torch.tanh(self.dense(first.to(self.dense.weight.dtype)))
 
 
 class BertModel(nn.Module):
@@ -311,6 +314,41 @@ class _ClassifierBase(nn.Module):
         self.config = cfg
         self.num_labels = cfg.num_labels
         self.arena = None  # ParamArena once adopted
+        self.runtime = None  # ops.fused.NativeRuntime once the native path is enabled
+        self._head_native = None
+
+    def arena_segments(self, prefix: str = ""):
+        from ..ops.arena import bert_segments
+
+        return bert_segments(self, prefix)
+
+    def enable_native(self, arena, seed: int = 0, prefix: str = "", runtime=None):
+        """Route embeddings / layers / pooler / head through the gfx950 kernels.  `arena` must hold this
+        model's parameters with a 16-bit compute copy."""
+        from ..ops import fused
+
+        if arena.p16 is None:
+            raise ValueError("the native path needs a 16-bit compute copy (fp16 or bf16 mode)")
+        cfg = self.config
+        if cfg.head_dim != 64:
+            raise ValueError("native attention kernels are specialised for head_dim == 64")
+        rt = runtime or fused.NativeRuntime(arena, seed)
+        self.arena, self.runtime = arena, rt
+        base = self.base_model
+        bp = f"{prefix}{self.base_model_prefix}."
+        if base.embeddings is not None:
+            base.embeddings._native = fused.EmbedNative(arena, bp + "embeddings.", cfg,
+                                                        arena.seg_index[f"{prefix}embeddings"], rt)
+        for lyr in base.encoder.layers():
+            lyr._native = fused.LayerNative(arena, f"{bp}encoder.layer.{lyr.index}.", cfg,
+                                            arena.seg_index[f"{prefix}layer{lyr.index}"], rt)
+        if getattr(self, "with_head", False):
+            self._enable_native_head(arena, rt, prefix, arena.seg_index[f"{prefix}head"])
+        return rt
+
+    def _begin_forward(self):
+        if self.runtime is not None and self.training and torch.is_grad_enabled():
+            self.runtime.next_micro()
 
     @property
     def base_model(self) -> BertModel:
@@ -365,14 +403,29 @@ class BertForSequenceClassification(_ClassifierBase):
             self.classifier = nn.Linear(cfg.hidden_size, cfg.num_labels)
         self.init_weights()
 
+    def _enable_native_head(self, arena, rt, prefix, seg):
+        from ..ops import fused
+
+        H, bp = self.config.hidden_size, f"{prefix}bert."
+        self.bert.pooler._native = fused.DenseNative(arena, bp + "pooler.dense.weight", bp + "pooler.dense.bias", H, seg, rt)
+        self._head_native = fused.HeadNative(arena, f"{prefix}classifier.weight", f"{prefix}classifier.bias",
+                                             self.num_labels, H, seg, rt)
+
     def head(self, last_hidden: torch.Tensor, labels=None) -> SequenceClassifierOutput:
         pooled = self.bert.pooler(last_hidden)
+        if self._head_native is not None and pooled.is_cuda:
+            from ..ops import fused
+
+            logits, loss = fused.classifier_head(pooled, self._head_native, labels,
+                                                 self.config.head_dropout if self.training else 0.0)
+            return SequenceClassifierOutput(loss=loss, logits=logits)
         logits = self.classifier(self.dropout(pooled))
         loss = _ce_loss(logits, labels, self.num_labels) if labels is not None else None
         return SequenceClassifierOutput(loss=loss, logits=logits)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, **unused):
+        self._begin_forward()
         out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng)
         res = self.head(out.last_hidden_state, labels)
         res.hidden_states = out.hidden_states
@@ -387,7 +440,7 @@ class RobertaClassificationHead(nn.Module):
         self.out_proj = nn.Linear(cfg.hidden_size, cfg.num_labels)
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        x = self.dropout(features[:, 0].float())
+        x = self.dropout(features[:, 0].to(self.dense.weight.dtype))
         x = self.dropout(torch.tanh(self.dense(x)))
         return self.out_proj(x)
 
@@ -404,13 +457,30 @@ class RobertaForSequenceClassification(_ClassifierBase):
             self.classifier = RobertaClassificationHead(cfg)
         self.init_weights()
 
+    def _enable_native_head(self, arena, rt, prefix, seg):
+        from ..ops import fused
+
+        H, cp = self.config.hidden_size, f"{prefix}classifier."
+        self._dense_native = fused.DenseNative(arena, cp + "dense.weight", cp + "dense.bias", H, seg, rt)
+        self._head_native = fused.HeadNative(arena, cp + "out_proj.weight", cp + "out_proj.bias", self.num_labels, H,
+                                             seg, rt)
+
     def head(self, last_hidden: torch.Tensor, labels=None) -> SequenceClassifierOutput:
+        if self._head_native is not None and last_hidden.is_cuda:
+            from ..ops import fused
+
+            p = self.config.head_dropout if self.training else 0.0
+            first = fused.dropout16(last_hidden[:, 0].contiguous(), self.runtime, p, fused.SITE_HEAD_PRE)
+            pooled = fused.dense_tanh(first, self._dense_native)
+            logits, loss = fused.classifier_head(pooled, self._head_native, labels, p)
+            return SequenceClassifierOutput(loss=loss, logits=logits)
         logits = self.classifier(last_hidden)
         loss = _ce_loss(logits, labels, self.num_labels) if labels is not None else None
         return SequenceClassifierOutput(loss=loss, logits=logits)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, **unused):
+        self._begin_forward()
         out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng)
         res = self.head(out.last_hidden_state, labels)
         res.hidden_states = out.hidden_states

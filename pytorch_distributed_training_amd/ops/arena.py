@@ -1,0 +1,214 @@
+"""Flat parameter / gradient arenas.
+
+All parameters of a model are re-homed into ONE contiguous fp32 "master" tensor, their gradients into
+a second one of the same layout, and (for 16-bit training) a third tensor holds the fp16/bf16 compute
+copy that the kernels read.  Consequences, all of them the point of the design:
+
+* the fused AdamW is a single kernel over the whole model (or one per bucket);
+* a data-parallel bucket is a contiguous *slice* of the gradient arena - the weight-gradient kernels
+  write straight into it, and RCCL reduces it in place (no bucket copy-in / copy-out as in torch DDP,
+  whose reducer the reference relies on at /root/reference/test_data_parallelism.py:125-127);
+* Q, K and V weights are adjacent, so one ``[3H, H]`` view is the fused QKV GEMM weight;
+* ``state_dict()`` still shows the HF names, because ``nn.Parameter.data`` are views into the arena.
+
+The arena is laid out in REVERSE forward order (head, last layer, ..., first layer, embeddings):
+address order == the order in which backward finishes gradients == bucket launch order.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+ALIGN = 64  # elements; 256 B in fp32, 128 B in 16-bit
+
+
+@dataclass
+class Segment:
+    """A run of parameters that becomes gradient-complete at one point of backward."""
+
+    name: str
+    params: List[Tuple[str, nn.Parameter]]
+    start: int = 0
+    end: int = 0
+    bucket: int = -1
+    # gradients of this segment are produced by native kernels that can overwrite (beta=0) on the first
+    # backward after zero_grad, so the slice needs no memset
+    native_overwrite: bool = False
+
+
+def _align(n: int) -> int:
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+def default_segments(model: nn.Module, cap_elems: int = 6 << 20) -> List[Segment]:
+    """Generic fallback: registration order cut into ~25 MB (fp32) runs, like DDP's bucket cap."""
+    segs: List[Segment] = []
+    cur: List[Tuple[str, nn.Parameter]] = []
+    size = 0
+    for name, p in model.named_parameters():
+        cur.append((name, p))
+        size += p.numel()
+        if size >= cap_elems:
+            segs.append(Segment(f"seg{len(segs)}", cur))
+            cur, size = [], 0
+    if cur:
+        segs.append(Segment(f"seg{len(segs)}", cur))
+    return segs
+
+
+def bert_segments(model, prefix: str = "") -> List[Segment]:
+    """Forward-ordered segments of a (possibly stage-sliced) BERT/RoBERTa classifier."""
+    base = model.base_model
+    bp = f"{prefix}{model.base_model_prefix}."
+    segs: List[Segment] = []
+    if base.embeddings is not None:
+        e = base.embeddings
+        segs.append(Segment(f"{prefix}embeddings", [
+            (f"{bp}embeddings.word_embeddings.weight", e.word_embeddings.weight),
+            (f"{bp}embeddings.position_embeddings.weight", e.position_embeddings.weight),
+            (f"{bp}embeddings.token_type_embeddings.weight", e.token_type_embeddings.weight),
+            (f"{bp}embeddings.LayerNorm.weight", e.LayerNorm.weight),
+            (f"{bp}embeddings.LayerNorm.bias", e.LayerNorm.bias),
+        ], native_overwrite=True))
+    for lyr in base.encoder.layers():
+        lp = f"{bp}encoder.layer.{lyr.index}."
+        segs.append(Segment(f"{prefix}layer{lyr.index}", [(lp + n, p) for n, p in lyr.arena_order()],
+                            native_overwrite=True))
+    head: List[Tuple[str, nn.Parameter]] = []
+    if base.pooler is not None:
+        head += [(f"{bp}pooler.dense.weight", base.pooler.dense.weight), (f"{bp}pooler.dense.bias", base.pooler.dense.bias)]
+    if getattr(model, "with_head", False):
+        head += [(f"{prefix}classifier.{n}", p) for n, p in model.classifier.named_parameters()]
+    if head:
+        segs.append(Segment(f"{prefix}head", head))
+    return segs
+
+
+class ParamArena:
+    def __init__(self, model: nn.Module, device: torch.device, compute_dtype: Optional[torch.dtype] = None,
+                 min_bucket_elems: int = 1 << 20, segments: Optional[List[Segment]] = None):
+        self.model = model
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        if segments is None:
+            segments = model.arena_segments() if hasattr(model, "arena_segments") else default_segments(model)
+        named = dict(model.named_parameters())
+        listed = {id(p) for s in segments for _, p in s.params}
+        missing = [n for n, p in named.items() if id(p) not in listed]
+        if missing:
+            raise ValueError(f"arena_segments() does not cover parameters: {missing[:5]} ...")
+        # reverse forward order => address order is gradient-completion order
+        self.segments: List[Segment] = list(reversed(segments))
+        off = 0
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        seen = set()
+        for seg in self.segments:
+            seg.start = off
+            for name, p in seg.params:
+                if id(p) in seen:
+                    raise ValueError(f"parameter {name} appears twice (tied weights are not supported)")
+                seen.add(id(p))
+                self.offsets[name] = (off, p.numel())
+                off = _align(off + p.numel()) if p.numel() % ALIGN else off + p.numel()
+            off = _align(off)
+            seg.end = off
+        self.numel = off
+        f32 = dict(device=self.device, dtype=torch.float32)
+        self.master = torch.zeros(self.numel, **f32)
+        self.grad = torch.zeros(self.numel, **f32)
+        self.p16 = torch.zeros(self.numel, device=self.device, dtype=compute_dtype) if compute_dtype else None
+        with torch.no_grad():
+            for seg in self.segments:
+                for name, p in seg.params:
+                    o, n = self.offsets[name]
+                    view = self.master[o:o + n].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view
+                    p.grad = self.grad[o:o + n].view(p.shape)
+        # buckets: merge small neighbouring segments (e.g. the ~1 M-parameter head joins the last layer)
+        self.bucket_bounds: List[int] = [0]
+        self.bucket_segments: List[int] = []
+        count = 0
+        for i, seg in enumerate(self.segments):
+            seg.bucket = len(self.bucket_bounds) - 1
+            count += 1
+            last = i == len(self.segments) - 1
+            if seg.end - self.bucket_bounds[-1] >= min_bucket_elems or last:
+                self.bucket_bounds.append(seg.end)
+                self.bucket_segments.append(count)
+                count = 0
+        if len(self.bucket_bounds) > 2 and self.bucket_bounds[-1] - self.bucket_bounds[-2] < min_bucket_elems:
+            # a small tail joins the previous bucket
+            self.bucket_bounds.pop(-2)
+            self.bucket_segments[-2] += self.bucket_segments[-1]
+            self.bucket_segments.pop()
+            for seg in self.segments:
+                seg.bucket = min(seg.bucket, len(self.bucket_bounds) - 2)
+        self.written = [False] * len(self.segments)  # gradient slice holds this step's values already
+        self.seg_index = {s.name: i for i, s in enumerate(self.segments)}
+        self.param_segment: Dict[int, int] = {id(p): i for i, s in enumerate(self.segments) for _, p in s.params}
+        if self.p16 is not None:
+            self.sync_compute_copy()
+
+    # ------------------------------------------------------------------------------------------
+    def view16(self, name: str, shape: Sequence[int], count: int = 1) -> torch.Tensor:
+        """16-bit view starting at parameter `name`, spanning `count` adjacent parameters."""
+        o, _ = self.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return self.p16[o:o + n].view(*shape)
+
+    def gview(self, name: str, shape: Sequence[int]) -> torch.Tensor:
+        o, _ = self.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return self.grad[o:o + n].view(*shape)
+
+    def mview(self, name: str, shape: Sequence[int]) -> torch.Tensor:
+        o, _ = self.offsets[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return self.master[o:o + n].view(*shape)
+
+    def adjacent(self, names: Sequence[str]) -> bool:
+        pos = None
+        for n in names:
+            o, k = self.offsets[n]
+            if pos is not None and o != pos:
+                return False
+            pos = o + k
+        return True
+
+    def sync_compute_copy(self) -> None:
+        """Refresh the 16-bit compute copy from the fp32 master (after init / checkpoint load)."""
+        if self.p16 is None:
+            return
+        if self.master.is_cuda:
+            from . import native
+
+            native().cast_to_16(self.master, self.p16)
+        else:
+            self.p16.copy_(self.master)
+
+    def zero_grad(self) -> None:
+        """Start a new accumulation window.  Slices whose producers overwrite on first touch are not memset."""
+        for i, seg in enumerate(self.segments):
+            self.written[i] = False
+            if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):
+                self.grad[seg.start:seg.end].zero_()
+
+    def take_accumulate_flag(self, seg_idx: int) -> bool:
+        """True if the native producer must add to the slice, False if it may overwrite it."""
+        acc = self.written[seg_idx]
+        self.written[seg_idx] = True
+        return acc
+
+    def state_bytes(self) -> int:
+        per = 8 + (self.p16.element_size() if self.p16 is not None else 0)
+        return self.numel * per

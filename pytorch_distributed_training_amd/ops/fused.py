@@ -1,0 +1,258 @@
+"""Coarse autograd nodes over the native kernels.
+
+PyTorch autograd is kept only as the OUTER tape: embeddings, each encoder layer, the pooler and the
+classification head are one node each.  A node's backward writes parameter gradients straight into the
+gradient arena (overwriting on the first micro-batch of an accumulation window, adding afterwards) and
+tells the runtime that its arena segment is complete, which is what lets the bucket reducer start the
+all-reduce of a layer while backward is still running on the layers below it.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from . import native
+from .arena import ParamArena
+
+SITE_EMBED = 0x7F000000
+SITE_HEAD = 0x7F000010
+SITE_HEAD_PRE = 0x7F000011
+
+
+class NativeRuntime:
+    """Per-model state shared by the native nodes: RNG stream, micro-batch counter, completion hook."""
+
+    def __init__(self, arena: ParamArena, seed: int = 0):
+        self.arena = arena
+        self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=arena.device)
+        self.micro = 0  # global micro-batch counter; part of every dropout counter
+        self.segment_done: Optional[Callable[[int], None]] = None  # set by the DP reducer wrapper
+
+    def reseed(self, seed: int) -> None:
+        self.rng_state[0] = seed
+
+    def next_micro(self) -> int:
+        self.micro = (self.micro + 1) & 0x7FFFFFFF
+        return self.micro
+
+    def done(self, seg: int) -> None:
+        if self.segment_done is not None:
+            self.segment_done(seg)
+
+
+class LayerNative:
+    """16-bit weight views and fp32 gradient views of one encoder layer, in the order csrc expects."""
+
+    def __init__(self, arena: ParamArena, prefix: str, cfg, segment: int, runtime: NativeRuntime):
+        H, Fd = cfg.hidden_size, cfg.intermediate_size
+        a = prefix + "attention."
+        qkv_w = [a + f"self.{n}.weight" for n in ("query", "key", "value")]
+        qkv_b = [a + f"self.{n}.bias" for n in ("query", "key", "value")]
+        if not (arena.adjacent(qkv_w) and arena.adjacent(qkv_b)):
+            raise RuntimeError("Q/K/V parameters are not adjacent in the arena")
+        spec = [
+            (qkv_w[0], (3 * H, H)), (qkv_b[0], (3 * H,)),
+            (a + "output.dense.weight", (H, H)), (a + "output.dense.bias", (H,)),
+            (a + "output.LayerNorm.weight", (H,)), (a + "output.LayerNorm.bias", (H,)),
+            (prefix + "intermediate.dense.weight", (Fd, H)), (prefix + "intermediate.dense.bias", (Fd,)),
+            (prefix + "output.dense.weight", (H, Fd)), (prefix + "output.dense.bias", (H,)),
+            (prefix + "output.LayerNorm.weight", (H,)), (prefix + "output.LayerNorm.bias", (H,)),
+        ]
+        self.w: List[torch.Tensor] = [arena.view16(n, s) for n, s in spec]
+        self.g: List[torch.Tensor] = [arena.gview(n, s) for n, s in spec]
+        self.segment = segment
+        self.rt = runtime
+        self.arena = arena
+
+
+class _LayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, layer, mask):
+        nat: LayerNative = layer._native
+        cfg = layer.cfg
+        B, S, H = x.shape
+        m, kvl = mask.native()
+        train = layer.training
+        micro = nat.rt.micro
+        x2 = x.reshape(B * S, H)
+        outs = native().layer_forward(
+            x2, m, kvl, nat.w, nat.rt.rng_state, B, S, cfg.num_attention_heads,
+            cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
+            cfg.layer_norm_eps, micro, layer.index)
+        ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl), x2, outs[1:]
+        ctx.meta = (B, S, H, train, micro)
+        return outs[0].view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        nat: LayerNative = layer._native
+        cfg = layer.cfg
+        B, S, H, train, micro = ctx.meta
+        acc = nat.arena.take_accumulate_flag(nat.segment)
+        dx = native().layer_backward(
+            dy.reshape(B * S, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, nat.rt.rng_state,
+            B, S, cfg.num_attention_heads,
+            cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
+            micro, layer.index, acc)
+        ctx.saved = None
+        nat.rt.done(nat.segment)
+        return dx.view(B, S, H), None, None
+
+
+def encoder_layer_forward(layer, hidden, mask, rng=None):
+    nat = layer._native
+    if hidden.dtype != nat.w[0].dtype:
+        hidden = hidden.to(nat.w[0].dtype)
+    if not hidden.requires_grad and torch.is_grad_enabled():
+        # the stack must stay on the tape even when its input is a constant (e.g. a pipeline stage whose
+        # input arrived from the previous rank): parameter gradients are produced inside backward()
+        hidden = hidden.detach().requires_grad_()
+    return _LayerFn.apply(hidden.contiguous(), layer, mask)
+
+
+# --------------------------------------------------------------------------------------------------
+class EmbedNative:
+    def __init__(self, arena: ParamArena, prefix: str, cfg, segment: int, runtime: NativeRuntime):
+        V, P, R, H = cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size, cfg.hidden_size
+        spec = [
+            (prefix + "word_embeddings.weight", (V, H)), (prefix + "position_embeddings.weight", (P, H)),
+            (prefix + "token_type_embeddings.weight", (R, H)), (prefix + "LayerNorm.weight", (H,)),
+            (prefix + "LayerNorm.bias", (H,)),
+        ]
+        self.w = [arena.view16(n, s) for n, s in spec]
+        self.g = [arena.gview(n, s) for n, s in spec]
+        self.segment, self.rt, self.arena = segment, runtime, arena
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, emb, ids, type_ids, pos_ids, inputs_embeds):
+        nat: EmbedNative = emb._native
+        cfg = emb.cfg
+        B, S = pos_ids.shape
+        train = emb.training
+        micro = nat.rt.micro
+        idf = ids.reshape(-1).contiguous() if ids is not None else None
+        ie = inputs_embeds.reshape(B * S, -1).contiguous() if inputs_embeds is not None else None
+        pf, tf = pos_ids.reshape(-1).contiguous(), type_ids.reshape(-1).contiguous()
+        y, pre, stats = native().embed_forward(idf, pf, tf, ie, *nat.w, nat.rt.rng_state, cfg.layer_norm_eps,
+                                               cfg.hidden_dropout_prob if train else 0.0, micro, SITE_EMBED)
+        ctx.emb, ctx.idx, ctx.saved = emb, (idf, pf, tf), (pre, stats)
+        ctx.meta = (B, S, train, micro, ie is not None)
+        return y.view(B, S, cfg.hidden_size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        emb = ctx.emb
+        nat: EmbedNative = emb._native
+        cfg = emb.cfg
+        B, S, train, micro, has_ie = ctx.meta
+        idf, pf, tf = ctx.idx
+        pre, stats = ctx.saved
+        acc = nat.arena.take_accumulate_flag(nat.segment)
+        dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.g,
+                                       nat.rt.rng_state, cfg.hidden_dropout_prob if train else 0.0, micro,
+                                       SITE_EMBED, cfg.pad_token_id, acc)
+        ctx.saved = None
+        nat.rt.done(nat.segment)
+        return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None)
+
+
+def embeddings_forward(emb, input_ids, token_type_ids, pos_ids, inputs_embeds, rng=None):
+    nat: EmbedNative = emb._native
+    if inputs_embeds is not None and inputs_embeds.dtype != nat.w[0].dtype:
+        inputs_embeds = inputs_embeds.to(nat.w[0].dtype)
+    # `anchor` ties the node to the tape: its gradient is never materialised (grads go to the arena)
+    anchor = emb.LayerNorm.weight
+    return _EmbedFn.apply(anchor, emb, None if inputs_embeds is not None else input_ids, token_type_ids, pos_ids,
+                          inputs_embeds)
+
+
+# --------------------------------------------------------------------------------------------------
+class DenseNative:
+    """A Linear(H,H)+tanh evaluated on token 0 (BERT pooler / RoBERTa head dense)."""
+
+    def __init__(self, arena: ParamArena, wname: str, bname: str, H: int, segment: int, runtime: NativeRuntime):
+        self.w, self.b = arena.view16(wname, (H, H)), arena.view16(bname, (H,))
+        self.gw, self.gb = arena.gview(wname, (H, H)), arena.gview(bname, (H,))
+        self.segment, self.rt, self.arena = segment, runtime, arena
+
+
+class _DenseTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, nat):
+        out = native().dense_tanh_forward(first, nat.w, nat.b)
+        ctx.nat, ctx.first, ctx.out = nat, first, out
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        nat: DenseNative = ctx.nat
+        out = ctx.out
+        dpre = (dout.float() * (1.0 - out.float() ** 2)).to(out.dtype)
+        dfirst = native().dense_backward(dpre.contiguous(), ctx.first, nat.w, nat.gw, nat.gb, True)
+        nat.rt.done(nat.segment)  # the dense layer is the last producer of the head segment in backward order
+        return dfirst, None
+
+
+def dense_tanh(first_tok: torch.Tensor, nat: DenseNative) -> torch.Tensor:
+    """tanh(first_tok @ W^T + b) for a [B, H] (possibly strided) 16-bit view of token 0."""
+    if not first_tok.requires_grad and torch.is_grad_enabled():
+        first_tok = first_tok.detach().requires_grad_()
+    return _DenseTanhFn.apply(first_tok, nat)
+
+
+class HeadNative:
+    def __init__(self, arena: ParamArena, wname: str, bname: str, C: int, H: int, segment: int, runtime: NativeRuntime):
+        self.w, self.b = arena.mview(wname, (C, H)), arena.mview(bname, (C,))
+        self.gw, self.gb = arena.gview(wname, (C, H)), arena.gview(bname, (C,))
+        self.segment, self.rt, self.arena = segment, runtime, arena
+
+
+class _HeadFn(torch.autograd.Function):
+    """dropout -> classifier -> mean cross-entropy; returns (logits, loss)."""
+
+    @staticmethod
+    def forward(ctx, pooled, nat, labels, p, site):
+        micro = nat.rt.micro
+        logits, loss = native().head_forward(pooled, nat.w, nat.b, labels, nat.rt.rng_state, p, micro, site)
+        ctx.nat, ctx.pooled, ctx.logits, ctx.labels = nat, pooled, logits, labels
+        ctx.meta = (p, micro, site)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None instead of a zero tensor
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, dlogits, dloss):
+        nat: HeadNative = ctx.nat
+        p, micro, site = ctx.meta
+        dp = native().head_backward(dloss if ctx.labels is not None else None, dlogits, ctx.pooled, nat.w, ctx.logits,
+                                    ctx.labels, nat.gw, nat.gb, nat.rt.rng_state, p, micro, site, True, False)
+        return dp, None, None, None, None
+
+
+def classifier_head(pooled: torch.Tensor, nat: HeadNative, labels: Optional[torch.Tensor], p: float,
+                    site: int = SITE_HEAD):
+    """(logits fp32 [B,C], loss or None) from a 16-bit pooled [B,H]."""
+    logits, loss = _HeadFn.apply(pooled.contiguous(), nat, labels, p, site)
+    return logits, (loss if labels is not None else None)
+
+
+def dropout16(x: torch.Tensor, rt: NativeRuntime, p: float, site: int) -> torch.Tensor:
+    """Counter-based dropout of a 16-bit tensor (same mask on forward and backward by construction)."""
+    if p <= 0.0:
+        return x
+    return _DropFn.apply(x, rt, p, site)
+
+
+class _DropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rt, p, site):
+        ctx.rt, ctx.meta = rt, (p, rt.micro, site)
+        return native().dropout16(x, rt.rng_state, p, rt.micro, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, micro, site = ctx.meta
+        return native().dropout16(dy, ctx.rt.rng_state, p, micro, site), None, None, None

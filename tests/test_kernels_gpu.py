@@ -299,7 +299,7 @@ def test_head_fwd_bwd(dtype):
     torch.testing.assert_close(loss, rloss, rtol=1e-5, atol=1e-5)
     (rloss * 3.0).backward()
     gW, gb = torch.zeros_like(W), torch.zeros_like(bias)
-    dp = C().head_backward(torch.tensor(3.0, device="cuda"), pooled, W, logits, labels, gW, gb, st, 0.0, 0, 0, False, False)
+    dp = C().head_backward(torch.tensor(3.0, device="cuda"), None, pooled, W, logits, labels, gW, gb, st, 0.0, 0, 0, False, False)
     assert rel_err(dp, pf.grad) < 1e-2
     assert rel_err(gW, Wf.grad) < 1e-4
     assert rel_err(gb, bf.grad) < 1e-4
