@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BERT-large sequence-classification fine-tuning throughput (samples/s, whole job).
+
+The configuration is the reference's data-parallel launch (bert-large-cased, MRPC-shaped sentence pairs,
+16-bit mixed precision, AdamW lr 2e-5 with linear warm-up, dropout 0.1;
+/root/reference/test_data_parallelism.py:69-150,174) on synthetic token batches of seq 128 with random-init
+weights.  Every timed step is a full optimizer step: forward, backward (with the bucketed gradient
+all-reduce when N > 1), fused AdamW with dynamic loss scaling, LR schedule, zero_grad.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from pytorch_distributed_training_amd.data.synthetic import fixed_batch  # noqa: E402
+from pytorch_distributed_training_amd.engine import Engine  # noqa: E402
+from pytorch_distributed_training_amd.models.bert import build_model  # noqa: E402
+from pytorch_distributed_training_amd.optim import AdamW, get_linear_schedule_with_warmup  # noqa: E402
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="bert-large-cased")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU samples per optimizer step")
+    ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    comm = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[args.comm_dtype]
+    eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm)
+    if eng.device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU")
+    torch.manual_seed(42)
+    model = build_model(args.model)
+    optimizer = AdamW(params=model.parameters(), lr=2e-5, correct_bias=True)
+    model, optimizer = eng.prepare(model, optimizer)
+    sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
+    model.train()
+    micro = args.batch // args.accum
+    vocab = eng.unwrap_model(model).config.vocab_size
+    pool = [fixed_batch(micro, args.seq_len, vocab, eng.device, seed=1000 * eng.process_index + i) for i in range(4)]
+
+    def step(i: int) -> torch.Tensor:
+        loss = None
+        for a in range(args.accum):
+            batch = pool[(i * args.accum + a) % len(pool)]
+            last = a == args.accum - 1
+            ctx = eng.no_sync(model) if not last else _null()
+            with ctx:
+                out = model(**batch)
+                loss = out.loss / args.accum
+                eng.backward(loss)
+        optimizer.step()
+        sched.step()
+        optimizer.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    _fence(eng)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    _fence(eng)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    global_batch = args.batch * world
+    value = global_batch * args.steps / dt
+    if eng.is_main_process:
+        print(json.dumps({
+            "metric": "training samples/sec (node) BERT-large seq128",
+            "value": round(value, 2),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic MRPC-shaped token batches (random-init weights)",
+            "final_loss": float(loss.item()) * args.accum,
+            "tokens_per_s": round(value * args.seq_len, 1),
+            "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
+                       "micro_batches": args.accum, "seq_len": args.seq_len,
+                       "parallelism": f"dp{world}", "optimizer": "fused AdamW + dynamic loss scale",
+                       "dropout": 0.1},
+        }))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _fence(eng: Engine) -> None:
+    if eng.num_processes > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Process bootstrap: the launcher contract of the reference, kept.
+
+* ``python -m torch.distributed.run --nproc_per_node N --use_env script.py --fp16=True``
+  (/root/reference/README.md:12-14): torchrun exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+  MASTER_PORT and :func:`init_distributed` consumes them.
+* ``python script.py`` self-spawning one process per GPU on ``127.0.0.1:29500``
+  (/root/reference/test_model_parallelism.py:166-171,331-335): :func:`spawn`.
+
+One process drives one GPU.  The backend is "nccl" (RCCL over xGMI on ROCm) for GPU runs and "gloo"
+for the CPU plumbing configuration.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistEnv:
+    rank: int = 0
+    local_rank: int = 0
+    world_size: int = 1
+    master_addr: str = "127.0.0.1"
+    master_port: int = 29500
+
+    @classmethod
+    def from_environ(cls) -> "DistEnv":
+        e = os.environ
+        return cls(int(e.get("RANK", 0)), int(e.get("LOCAL_RANK", e.get("RANK", 0))), int(e.get("WORLD_SIZE", 1)),
+                   e.get("MASTER_ADDR", "127.0.0.1"), int(e.get("MASTER_PORT", 29500)))
+
+    def export(self) -> None:
+        os.environ.update(RANK=str(self.rank), LOCAL_RANK=str(self.local_rank), WORLD_SIZE=str(self.world_size),
+                          MASTER_ADDR=self.master_addr, MASTER_PORT=str(self.master_port))
+
+
+def pick_device(cpu: bool, local_rank: int) -> torch.device:
+    if cpu or not torch.cuda.is_available():
+        return torch.device("cpu")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    return torch.device("cuda", local_rank % torch.cuda.device_count())
+
+
+def init_distributed(cpu: bool = False, backend: Optional[str] = None, timeout_s: int = 1800,
+                     env: Optional[DistEnv] = None) -> Tuple[DistEnv, torch.device]:
+    """Join (or create) the default process group described by the environment; idempotent."""
+    env = env or DistEnv.from_environ()
+    device = pick_device(cpu, env.local_rank)
+    if env.world_size > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        env.export()
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = device  # eager communicator creation, binds the rank to its GPU
+        dist.init_process_group(backend, rank=env.rank, world_size=env.world_size,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    return env, device
+
+
+def shutdown() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _spawn_entry(local_rank: int, fn: Callable, world_size: int, addr: str, port: int, args: tuple) -> None:
+    DistEnv(local_rank, local_rank, world_size, addr, port).export()
+    fn(local_rank, world_size, *args)
+
+
+def spawn(fn: Callable, args: tuple = (), nprocs: Optional[int] = None, master_addr: str = "127.0.0.1",
+          master_port: int = 29500, join: bool = True):
+    """``mp.spawn``-style self launch: ``fn(rank, world_size, *args)`` in ``nprocs`` children
+    (default: one per visible GPU, at least one)."""
+    import torch.multiprocessing as mp
+
+    if nprocs is None:
+        nprocs = max(1, torch.cuda.device_count())
+    return mp.spawn(_spawn_entry, args=(fn, nprocs, master_addr, master_port, args), nprocs=nprocs, join=join)
+
+
+def find_free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

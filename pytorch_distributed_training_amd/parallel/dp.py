@@ -1,0 +1,189 @@
+"""Data parallelism: replicated parameters + bucketed gradient all-reduce overlapped with backward.
+
+This is the role torch ``DistributedDataParallel`` plays in the reference
+(/root/reference/test_data_parallelism.py:125-127 through Accelerate; explicitly with
+``device_ids=None, output_device=None, find_unused_parameters=True`` and ``no_sync()`` at
+/root/reference/test_model_parallelism.py:248-253,292-296).  Differences by design:
+
+* buckets are contiguous slices of the model's flat gradient arena (one encoder layer each), reduced
+  in place by the C++ ``GradBucketReducer`` (csrc/runtime/reducer.cpp) through RCCL ("nccl" backend)
+  or gloo (CPU plumbing);
+* readiness is signalled per arena *segment* by the native backward nodes (or per parameter by autograd
+  hooks on the PyTorch path) - there is no per-iteration autograd-graph walk for unused parameters: a
+  bucket nobody completed is still reduced at the end of backward, so ``find_unused_parameters`` is
+  always "on" at zero cost;
+* no float buffers exist in BERT, so there is no per-forward buffer broadcast.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..ops.arena import ParamArena
+
+
+class _PyReducer:
+    """Pure-Python mirror of the C++ reducer (used only if the extension cannot be loaded on a CPU box)."""
+
+    def __init__(self, pg, arena_grad, bounds, expected, average=True, comm_dtype=0):
+        self.pg, self.bounds, self.expected, self.average = pg, bounds, expected, average
+        self.views = [arena_grad[bounds[i]:bounds[i + 1]] for i in range(len(expected))]
+        self.world = dist.get_world_size(pg)
+        self._reset()
+        self.sync, self.active = True, False
+        self._stats = {"steps": 0, "collectives": 0, "bytes": 0, "host_wait_us": 0}
+
+    def _reset(self):
+        self.ready = [0] * len(self.expected)
+        self.works = [None] * len(self.expected)
+        self.order: List[int] = []
+        self.next = 0
+
+    def begin(self, sync=True):
+        self._reset()
+        self.sync, self.active = sync, True
+
+    def _launch(self, b):
+        self.order.append(b)
+        if self.world == 1:
+            return
+        self.works[b] = dist.all_reduce(self.views[b], group=self.pg, async_op=True)
+        self._stats["collectives"] += 1
+        self._stats["bytes"] += self.views[b].numel() * 4
+
+    def mark_ready(self, bucket, count=1):
+        if not (self.active and self.sync):
+            return
+        self.ready[bucket] += count
+        while self.next < len(self.expected) and self.ready[self.next] >= self.expected[self.next]:
+            self._launch(self.next)
+            self.next += 1
+
+    def finish(self):
+        if not self.active:
+            return
+        self.active = False
+        if not self.sync:
+            return
+        for b in range(self.next, len(self.expected)):
+            self._launch(b)
+        for b, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                if self.average:
+                    self.views[b].div_(self.world)
+        self._stats["steps"] += 1
+
+    def broadcast(self, tensor, root=0, chunk_elems=16 << 20):
+        if self.world > 1:
+            dist.broadcast(tensor, src=dist.get_global_rank(self.pg, root) if self.pg is not None else root, group=self.pg)
+
+    def launch_order(self):
+        return list(self.order)
+
+    def stats(self):
+        return dict(self._stats)
+
+    def num_buckets(self):
+        return len(self.expected)
+
+
+def make_reducer(pg, arena: ParamArena, expected: List[int], average: bool = True, comm_dtype: Optional[torch.dtype] = None):
+    code = {None: 0, torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[comm_dtype]
+    from ..ops import available, native
+
+    if available():
+        return native().GradBucketReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+    if arena.device.type == "cuda":
+        native()  # raises with the build hint: never fall back silently on a GPU box
+    return _PyReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+
+
+class DataParallel(nn.Module):
+    """Wrap an arena-backed model for data-parallel training over `process_group`."""
+
+    def __init__(self, module: nn.Module, arena: ParamArena, process_group=None, comm_dtype: Optional[torch.dtype] = None,
+                 broadcast_from: Optional[int] = 0):
+        super().__init__()
+        self.module = module
+        self.arena = arena
+        self.pg = process_group if process_group is not None else dist.group.WORLD
+        self.world_size = dist.get_world_size(self.pg)
+        self.require_sync = True
+        self._armed = False
+        self._callback_queued = False
+        runtime = getattr(module, "runtime", None)
+        self.native_mode = runtime is not None
+        nb = len(arena.bucket_bounds) - 1
+        if self.native_mode:
+            expected = list(arena.bucket_segments)
+            seg_bucket = [s.bucket for s in arena.segments]
+            runtime.segment_done = lambda seg: self._mark(seg_bucket[seg])
+        else:
+            expected = [0] * nb
+            for seg in arena.segments:
+                for _, p in seg.params:
+                    if p.requires_grad:
+                        expected[seg.bucket] += 1
+                        p.register_post_accumulate_grad_hook(self._make_hook(seg.bucket))
+            expected = [max(1, e) for e in expected]
+        self.reducer = make_reducer(self.pg, arena, expected, True, comm_dtype)
+        if broadcast_from is not None and self.world_size > 1:
+            # rank-0 parameters to everyone (what DDP's constructor does), then refresh the 16-bit copy
+            self.reducer.broadcast(arena.master, broadcast_from)
+            arena.sync_compute_copy()
+
+    # -- reducer plumbing ----------------------------------------------------------------------------
+    def _make_hook(self, bucket: int):
+        def hook(_p):
+            self._mark(bucket)
+        return hook
+
+    def _mark(self, bucket: int) -> None:
+        if not self._armed:
+            return
+        if not self._callback_queued:
+            # end-of-backward callback, queued from inside the running backward pass
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+            self._callback_queued = True
+        self.reducer.mark_ready(bucket, 1)
+
+    def _finish(self) -> None:
+        self._callback_queued = False
+        if self._armed:
+            self._armed = False
+            self.reducer.finish()
+
+    def prepare_backward(self) -> None:
+        """Arm the reducer for the next backward pass (called from forward)."""
+        self.reducer.begin(self.require_sync)
+        self._armed = True
+        self._callback_queued = False
+
+    def finish_backward(self) -> None:
+        """Explicit end of backward for callers that do not go through autograd's callback (pipeline)."""
+        self._finish()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradients of backward passes inside the context only accumulate locally."""
+        old, self.require_sync = self.require_sync, False
+        try:
+            yield
+        finally:
+            self.require_sync = old
+
+    def forward(self, *args, **kwargs):
+        if self.training and torch.is_grad_enabled():
+            self.prepare_backward()
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)
