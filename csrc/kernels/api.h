@@ -43,7 +43,8 @@ typedef struct PdtGemm {
   int tiles_m, tiles_n, splits;
 } PdtGemm;
 
-// tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves), -1 = choose from the shape.
+// tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves, one barrier per K-tile), 2 = 256x256 ping-pong
+// (8 waves in two staggered groups, counted LDS-DMA waits), -1 = choose from the shape.
 // For TN, C is the fp32 slab buffer [splits][M][ldc] and g->splits / k_per_split select the K split
 // (0 = choose); the chosen values are written back into *g.
 int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);

@@ -68,6 +68,10 @@ struct GemmKernel {
         records = (uint32_t)(((size_t)(xavail - 1) * ld + klen) * 2);
         kstep = BK * 2;
       }
+      if (xavail <= 0) {  // the whole window lies outside the operand: every load must read as zero
+        base = X;
+        records = 0;
+      }
       rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {

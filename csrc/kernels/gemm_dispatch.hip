@@ -33,10 +33,13 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
   const int64_t b_bytes = 2ll * (layout == PDT_GEMM_NT ? 256ll * g->ldb : (int64_t)g->K * g->ldb);
   if (a_bytes >= 0x7FFF0000ll || b_bytes >= 0x7FFF0000ll) return -4;
   if (tile < 0) {
-    // 256x256 tiles (one workgroup per CU) once they fill the chip, else 128x128 at 2 workgroups per CU
+    // measured on MI355X (bench/gemm_bench.py, BERT-large shapes): the ping-pong 256x256 kernel wins for
+    // forward / dgrad once its tiles fill most of the 256 CUs; weight gradients (both operands read with
+    // transposed LDS reads) run faster on the single-barrier 256x256 kernel; small problems use 128x128
+    // tiles at two workgroups per CU
     const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-    tile = (t256 >= 160 || layout == PDT_GEMM_TN) ? 1 : 0;
-    if (layout == PDT_GEMM_TN && (g->M < 256 || g->N < 256)) tile = 0;
+    if (layout == PDT_GEMM_TN) tile = (g->M >= 256 && g->N >= 256) ? 1 : 0;
+    else tile = t256 >= 128 ? 2 : 0;
   }
   if (layout == PDT_GEMM_TN) {
     if (g->epi != PDT_EPI_SLAB_F32) return -5;
@@ -44,8 +47,9 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
     const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
     const int ktiles = (g->K + 63) / 64;
     if (g->splits <= 0) {
-      const int target = tile == 1 ? kNumCU : 2 * kNumCU;
-      int s = (target + tiles - 1) / tiles;
+      // one full round of workgroups: tiles * splits <= CUs (x2 for the 128x128 kernel, 2 workgroups per CU)
+      const int target = tile == 0 ? 2 * kNumCU : kNumCU;
+      int s = target / tiles;
       s = s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s);
       if (s > ktiles) s = ktiles;
       g->splits = s;

@@ -31,7 +31,7 @@ def rng_state(seed=1234, offset=0):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 384, 192), (1024, 768, 1024), (77, 128, 128)])
 def test_gemm_nt_plain_and_bias(dtype, tile, M, N, K):
     torch.manual_seed(0)
@@ -51,12 +51,13 @@ def test_gemm_nt_asymmetric_identity(dtype):
     n = 256
     A = torch.eye(n, device="cuda").to(dtype)
     W = (torch.arange(n * n, device="cuda").reshape(n, n) % 251).float().sub(125).div(16).to(dtype)
-    out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, 1)
-    assert torch.equal(out.float(), W.float().t())
+    for tile in (1, 2):
+        out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, tile)
+        assert torch.equal(out.float(), W.float().t())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 def test_gemm_nt_gelu_and_residual_epilogues(dtype, tile):
     torch.manual_seed(1)
     M, N, K = 520, 512, 256
@@ -84,8 +85,9 @@ def test_gemm_dropout_epilogue_statistics_and_replay(dtype):
     res = torch.zeros(M, N, device="cuda", dtype=dtype)
     st = rng_state(7, 3)
     z1 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 2, 5, 1)
-    z2 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 2, 5, 0)  # other tile shape: same mask
-    assert torch.equal(z1, z2)
+    for tile in (0, 2):  # other tile shapes: same mask
+        z2 = C().op_gemm("nt", A, W, 3, b, res, None, st, 0.1, 2, 5, tile)
+        assert torch.equal(z1, z2)
     keep = (z1 != 0).float().mean().item()
     assert abs(keep - 0.9) < 0.01
     assert abs(z1.float().max().item() - 1 / 0.9) < 2e-2
@@ -98,7 +100,7 @@ def test_gemm_dropout_epilogue_statistics_and_replay(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (333, 512, 768), (1024, 1024, 3072)])
 def test_gemm_nn_dgrad(dtype, tile, M, N, K):
     torch.manual_seed(2)
@@ -122,12 +124,13 @@ def test_gemm_nn_asymmetric_identity(dtype):
     n = 256
     A = torch.eye(n, device="cuda").to(dtype)
     W = (torch.arange(n * n, device="cuda").reshape(n, n) % 241).float().sub(120).div(16).to(dtype)
-    out = C().op_gemm("nn", A, W, 0, None, None, None, None, 0.0, 0, 0, 1)
-    assert torch.equal(out.float(), W.float())
+    for tile in (1, 2):
+        out = C().op_gemm("nn", A, W, 0, None, None, None, None, 0.0, 0, 0, tile)
+        assert torch.equal(out.float(), W.float())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("T,M,N", [(64, 256, 256), (1000, 512, 256), (4096, 768, 3072), (130, 128, 384)])
 def test_gemm_tn_wgrad(dtype, tile, T, M, N):
     torch.manual_seed(3)
@@ -338,3 +341,31 @@ def test_adamw_matches_hf_formula_and_skips_on_overflow():
     C().scaler_update(state, step, 2.0, 0.5, 2000, True)
     assert torch.equal(p, before)
     assert state[0].item() == scale / 2 and step.item() == 3 and state[3].item() == 1.0
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_pingpong_large_k_repeatable(layout):
+    """The 256x256 ping-pong kernel over many K-tiles, odd tile counts and ragged edges, run repeatedly:
+    every run must be bitwise identical (no LDS race) and match fp32."""
+    torch.manual_seed(10)
+    dtype = torch.float16
+    for (M, N, K) in [(512, 512, 4096), (700, 768, 1088), (256, 1024, 64), (1000, 264, 8192 + 64)]:
+        if layout == "tn":
+            A = (torch.randn(K, M - M % 8, device="cuda") * 0.3).to(dtype)
+            B = (torch.randn(K, N, device="cuda") * 0.3).to(dtype)
+            ref = A.float().t() @ B.float()
+            run = lambda: C().op_gemm_tn(A, B, None, False, 2, 0)
+        elif layout == "nt":
+            A = (torch.randn(M, K, device="cuda") * 0.3).to(dtype)
+            B = (torch.randn(N, K, device="cuda") * 0.3).to(dtype)
+            ref = A.float() @ B.float().t()
+            run = lambda: C().op_gemm("nt", A, B, 0, None, None, None, None, 0.0, 0, 0, 2)
+        else:
+            A = (torch.randn(M, K, device="cuda") * 0.3).to(dtype)
+            B = (torch.randn(K, N, device="cuda") * 0.3).to(dtype)
+            ref = A.float() @ B.float()
+            run = lambda: C().op_gemm("nn", A, B, 0, None, None, None, None, 0.0, 0, 0, 2)
+        first = run()
+        assert rel_err(first, ref) < 3e-3, (layout, M, N, K)
+        for _ in range(20):
+            assert torch.equal(run(), first), (layout, M, N, K)
