@@ -1,0 +1,97 @@
+"""Training configuration and command line.
+
+The reference has two ``type=bool`` flags (``--fp16`` / ``--cpu``, for which ANY non-empty string - even
+"False" - parses as True; /root/reference/test_data_parallelism.py:171-172) and otherwise hard-codes its
+hyper-parameters in a dict (``{"lr": 2e-5, "num_epochs": 3, "correct_bias": True, "seed": 42, "batch_size": 96}``,
+:174), module constants (``MAX_GPU_BATCH_SIZE = 8``, ``EVAL_BATCH_SIZE = 32``, :49-50) and literals (model
+name :69,112; 100 warm-up steps :133).  Here every one of those is a dataclass field with the reference's
+value as default and a CLI override; ``--fp16=True`` keeps working, ``--fp16=False`` now means False.
+"""
+from __future__ import annotations
+
+import argparse
+from dataclasses import asdict, dataclass, fields
+from typing import Optional
+
+
+def str2bool(v) -> bool:
+    if isinstance(v, bool):
+        return v
+    s = str(v).strip().lower()
+    if s in ("1", "true", "t", "yes", "y", "on", ""):
+        return True
+    if s in ("0", "false", "f", "no", "n", "off"):
+        return False
+    raise argparse.ArgumentTypeError(f"boolean expected, got {v!r}")
+
+
+@dataclass
+class TrainConfig:
+    # reference hyper-parameter dict
+    lr: float = 2e-5
+    num_epochs: int = 3
+    correct_bias: bool = True
+    seed: int = 42
+    batch_size: int = 96
+    # reference module constants
+    max_gpu_batch_size: int = 8
+    eval_batch_size: int = 32
+    # reference literals
+    model: str = "bert-large-cased"
+    num_warmup_steps: int = 100
+    # precision / device flags
+    fp16: bool = False
+    bf16: bool = False
+    cpu: bool = False
+    # data (no hub access: synthetic MRPC-shaped pairs unless a local TSV directory is given)
+    data_dir: Optional[str] = None
+    vocab_file: Optional[str] = None
+    train_examples: int = 3668
+    eval_examples: int = 408
+    max_length: Optional[int] = None  # None: pad to the longest sample of each batch
+    pad_to_multiple_of: Optional[int] = None
+    # behaviour switches
+    compat: bool = False        # reproduce the reference's quirks (see train_dp.py)
+    max_steps: int = 0          # stop after this many optimizer steps (0 = run all epochs)
+    log_every: int = 10
+    log_file: Optional[str] = None
+    # parallelism
+    pp_stages: int = 1          # 2 = layer-split model parallel composed with data parallel
+    micro_batches: int = 4      # pipeline micro-batches per accumulation window
+    mp_layout: str = "pipeline"  # "pipeline" (2-stage layer split) | "towers" (TriBert branch ensemble)
+    comm_dtype: Optional[str] = None  # None|fp16|bf16: wire dtype of the gradient all-reduce
+    min_bucket_mb: float = 4.0
+    # checkpointing
+    output_dir: Optional[str] = None
+    resume: Optional[str] = None
+    save_every: int = 0
+    init_from: Optional[str] = None  # directory with HF-layout weights (config.json + safetensors / bin)
+
+    def accumulation(self):
+        """The reference's accumulation policy (/root/reference/test_data_parallelism.py:90-93)."""
+        if self.batch_size > self.max_gpu_batch_size:
+            return self.batch_size // self.max_gpu_batch_size, self.max_gpu_batch_size
+        return 1, self.batch_size
+
+
+def build_parser(description: str = "MI355X-native distributed fine-tuning") -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description=description)
+    for f in fields(TrainConfig):
+        name = "--" + f.name.replace("_", "-")
+        alias = ["--" + f.name] if "_" in f.name else []
+        if f.type in (bool, "bool"):
+            p.add_argument(name, *alias, dest=f.name, type=str2bool, nargs="?", const=True, default=f.default)
+        else:
+            base = {"int": int, "float": float, "str": str, "Optional[int]": int, "Optional[str]": str,
+                    "Optional[float]": float}.get(str(f.type), str)
+            p.add_argument(name, *alias, dest=f.name, type=base, default=f.default)
+    return p
+
+
+def parse_config(argv=None, description: str = "MI355X-native distributed fine-tuning") -> TrainConfig:
+    ns = build_parser(description).parse_args(argv)
+    return TrainConfig(**vars(ns))
+
+
+def config_dict(cfg: TrainConfig):
+    return asdict(cfg)

@@ -1,0 +1,56 @@
+"""Multi-process test harness: run a function on N ranks over gloo on loopback (the way the reference
+self-launches with ``mp.spawn`` on 127.0.0.1, /root/reference/test_model_parallelism.py:166-171,333-335) and
+collect each rank's return value."""
+from __future__ import annotations
+
+import os
+import pickle
+import tempfile
+import traceback
+from typing import Any, Callable, List
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from .launch import DistEnv, find_free_port
+
+
+def _entry(rank: int, world: int, port: int, fn: Callable, args: tuple, outdir: str, backend: str) -> None:
+    DistEnv(rank, rank, world, "127.0.0.1", port).export()
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(2, world)))
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        res = fn(rank, world, *args)
+        with open(os.path.join(outdir, f"r{rank}.pkl"), "wb") as f:
+            pickle.dump(("ok", res), f)
+    except BaseException:  # noqa: BLE001 - report the traceback to the parent
+        with open(os.path.join(outdir, f"r{rank}.pkl"), "wb") as f:
+            pickle.dump(("err", traceback.format_exc()), f)
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def run_distributed(fn: Callable, world: int = 2, args: tuple = (), backend: str = "gloo") -> List[Any]:
+    """Spawn `world` processes, run ``fn(rank, world, *args)`` in each, return the per-rank results."""
+    with tempfile.TemporaryDirectory() as d:
+        port = find_free_port()
+        try:
+            mp.spawn(_entry, args=(world, port, fn, args, d, backend), nprocs=world, join=True)
+        except Exception:
+            msgs = []
+            for r in range(world):
+                p = os.path.join(d, f"r{r}.pkl")
+                if os.path.exists(p):
+                    kind, val = pickle.load(open(p, "rb"))
+                    if kind == "err":
+                        msgs.append(f"--- rank {r} ---\n{val}")
+            raise RuntimeError("distributed test failed:\n" + "\n".join(msgs))
+        out = []
+        for r in range(world):
+            kind, val = pickle.load(open(os.path.join(d, f"r{r}.pkl"), "rb"))
+            assert kind == "ok"
+            out.append(val)
+        return out

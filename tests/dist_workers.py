@@ -1,0 +1,148 @@
+"""Rank functions of the multi-process CPU tests (top-level so that mp.spawn can import them)."""
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from pytorch_distributed_training_amd.data import PadCollator, SyntheticPairDataset
+from pytorch_distributed_training_amd.engine import Engine, gather
+from pytorch_distributed_training_amd.models.bert import build_model
+from pytorch_distributed_training_amd.optim import AdamW
+
+
+def _model(seed=0):
+    torch.manual_seed(seed)
+    return build_model("bert-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+def _global_batch(n=8, s=12):
+    g = torch.Generator().manual_seed(123)
+    ids = torch.randint(1, 512, (n, s), generator=g)
+    mask = torch.ones(n, s, dtype=torch.long)
+    mask[1, 7:] = 0
+    return dict(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids),
+                labels=torch.randint(0, 2, (n,), generator=g))
+
+
+def dp_grads_match_big_batch(rank, world):
+    """DP gradients (average over ranks of per-shard mean loss) == gradients of the whole batch on one process."""
+    eng = Engine(cpu=True, min_bucket_mb=0.05)
+    model = _model(seed=rank)  # different init per rank: prepare() must broadcast rank 0's weights
+    model = eng.prepare(model)
+    ref = _model(seed=0)
+    inner = eng.unwrap_model(model)
+    for (n, p), (_, q) in zip(inner.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p, q), f"broadcast failed for {n}"
+    batch = _global_batch()
+    shard = {k: v[rank::world] for k, v in batch.items()}
+    model.train()
+    eng.backward(model(**shard).loss)
+    ref.train()
+    ref(**batch).loss.backward()
+    worst = 0.0
+    for (n, p), (_, q) in zip(inner.named_parameters(), ref.named_parameters()):
+        worst = max(worst, (p.grad - q.grad).abs().max().item())
+    order = model.reducer.launch_order()
+    nb = model.reducer.num_buckets()
+    return {"worst": worst, "order": list(order), "nb": nb, "stats": dict(model.reducer.stats())}
+
+
+def dp_no_sync_accumulation(rank, world):
+    """Two micro-batches, the first under no_sync: one reduction, equal to the 2-micro-batch big-batch gradient."""
+    eng = Engine(cpu=True, min_bucket_mb=0.05)
+    model = eng.prepare(_model())
+    inner = eng.unwrap_model(model)
+    batch = _global_batch(16)
+    model.train()
+    mb = [{k: v[i * 8:(i + 1) * 8][rank::world] for k, v in batch.items()} for i in range(2)]
+    with eng.no_sync(model):
+        eng.backward(model(**mb[0]).loss / 2)
+    local_only = inner.arena.grad.clone()
+    collectives_before = model.reducer.stats()["collectives"]
+    eng.backward(model(**mb[1]).loss / 2)
+    ref = _model()
+    ref.train()
+    (ref(**{k: v[:8] for k, v in batch.items()}).loss / 2).backward()
+    (ref(**{k: v[8:] for k, v in batch.items()}).loss / 2).backward()
+    worst = max((p.grad - q.grad).abs().max().item() for p, q in zip(inner.parameters(), ref.parameters()))
+    gathered = [torch.zeros_like(local_only) for _ in range(world)]
+    dist.all_gather(gathered, local_only)
+    differs = not torch.equal(gathered[0], gathered[1])
+    return {"worst": worst, "no_sync_kept_local": differs, "collectives_before": collectives_before,
+            "collectives_after": model.reducer.stats()["collectives"], "nb": model.reducer.num_buckets()}
+
+
+class _PartlyUsed(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 8)
+        self.unused = torch.nn.Linear(8, 8)
+        self.b = torch.nn.Linear(8, 2)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def dp_unused_parameters(rank, world):
+    """Parameters outside the graph (the reference needs find_unused_parameters=True for TriBert): the step
+    completes, their gradient stays zero, everything else is averaged."""
+    eng = Engine(cpu=True, min_bucket_mb=1e-5)
+    torch.manual_seed(0)
+    model = eng.prepare(_PartlyUsed())
+    x = torch.arange(32, dtype=torch.float32).reshape(4, 8) * (rank + 1)
+    model.train()
+    model(x).sum().backward()
+    inner = eng.unwrap_model(model)
+    ref = _PartlyUsed()
+    ref.load_state_dict(inner.state_dict())
+    tot = sum(ref(torch.arange(32, dtype=torch.float32).reshape(4, 8) * (r + 1)).sum() for r in range(world)) / world
+    tot.backward()
+    worst = max((p.grad - (q.grad if q.grad is not None else torch.zeros_like(q))).abs().max().item()
+                for p, q in zip(inner.parameters(), ref.parameters()))
+    return {"worst": worst, "unused_zero": bool(inner.unused.weight.grad.abs().sum() == 0),
+            "order": list(model.reducer.launch_order()), "nb": model.reducer.num_buckets()}
+
+
+def gather_semantics(rank, world):
+    t = torch.arange(3) + 10 * rank
+    out = {"vec": gather(t).tolist(), "scalar": gather(torch.tensor(rank)).tolist()}
+    nested = gather({"a": torch.full((2, 2), rank), "b": [torch.tensor([rank]), (torch.tensor([rank + 5]),)]})
+    out["nested_a"] = nested["a"].tolist()
+    out["nested_b0"] = nested["b"][0].tolist()
+    out["nested_b1_is_tuple"] = isinstance(nested["b"][1], tuple)
+    try:
+        gather("nope")
+    except TypeError:
+        out["type_error"] = True
+    return out
+
+
+def sharded_loader_and_training(rank, world):
+    """End-to-end DP recipe pieces on 2 ranks: sharded loader lengths, identical parameters after training."""
+    eng = Engine(cpu=True, seed=1)
+    ds = SyntheticPairDataset(50, vocab_size=512, min_len=3, max_len=8, seed=0)
+    dl = DataLoader(ds, shuffle=True, collate_fn=PadCollator(), batch_size=4)
+    model = _model()
+    opt = AdamW(params=model.parameters(), lr=1e-3)
+    model, opt, dl = eng.prepare(model, opt, dl)
+    n_batches, first_epoch_ids = len(dl), []
+    model.train()
+    for epoch in range(2):
+        for batch in dl:
+            if epoch == 0:
+                first_epoch_ids.append(batch["input_ids"][:, 1].tolist())
+            eng.backward(model(**batch).loss)
+            opt.step()
+            opt.zero_grad()
+    params = eng.unwrap_model(model).arena.master.clone()
+    both = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(both, params)
+    return {"len": n_batches, "same_params": bool(torch.equal(both[0], both[1])), "ids": first_epoch_ids}
+
+
+def dp_recipe(rank, world, tmp):
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.recipes import run_data_parallel
+
+    cfg = TrainConfig(model="bert-tiny", cpu=True, train_examples=48, eval_examples=20, num_epochs=2, batch_size=16,
+                      lr=1e-3, num_warmup_steps=2, log_every=100, output_dir=tmp if rank == 0 else tmp)
+    return run_data_parallel(cfg)

@@ -1,0 +1,62 @@
+"""Data-parallel plumbing on 2 CPU processes over gloo (the C++ bucket reducer runs unchanged on CPU tensors)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dist_workers as W  # noqa: E402
+from pytorch_distributed_training_amd.testing import run_distributed  # noqa: E402
+
+
+def test_native_reducer_is_loaded():
+    from pytorch_distributed_training_amd.ops import available
+
+    assert available(), "the C++ extension (bucket reducer) must be built: python build_ext.py"
+
+
+def test_dp_gradients_equal_single_process_big_batch():
+    res = run_distributed(W.dp_grads_match_big_batch, 2)
+    for r in res:
+        assert r["worst"] < 1e-6
+        assert r["nb"] >= 3
+        assert r["order"] == list(range(r["nb"]))  # buckets are launched in backward-completion order
+        assert r["stats"]["collectives"] == r["nb"]
+    assert res[0]["order"] == res[1]["order"]
+
+
+def test_dp_no_sync_accumulates_locally_then_reduces_once():
+    for r in run_distributed(W.dp_no_sync_accumulation, 2):
+        assert r["no_sync_kept_local"]
+        assert r["collectives_before"] == 0 and r["collectives_after"] == r["nb"]
+        assert r["worst"] < 1e-6
+
+
+def test_dp_with_unused_parameters():
+    for r in run_distributed(W.dp_unused_parameters, 2):
+        assert r["worst"] < 1e-6 and r["unused_zero"]
+        assert sorted(r["order"]) == list(range(r["nb"]))
+
+
+def test_gather_tensor_nested_and_scalar():
+    res = run_distributed(W.gather_semantics, 2)
+    for r in res:
+        assert r["vec"] == [0, 1, 2, 10, 11, 12]
+        assert r["scalar"] == [0, 1]
+        assert r["nested_a"] == [[0, 0], [0, 0], [1, 1], [1, 1]]
+        assert r["nested_b0"] == [0, 1] and r["nested_b1_is_tuple"] and r["type_error"]
+
+
+def test_sharded_loader_and_replicas_stay_in_sync():
+    res = run_distributed(W.sharded_loader_and_training, 2)
+    assert res[0]["len"] == res[1]["len"] == 7  # 13 batches of 4 -> 7 per rank (even batches)
+    assert res[0]["same_params"] and res[1]["same_params"]
+    assert res[0]["ids"] != res[1]["ids"]  # the two ranks saw different batches
+
+
+def test_data_parallel_recipe_two_ranks(tmp_path):
+    res = run_distributed(W.dp_recipe, 2, args=(str(tmp_path),))
+    assert res[0]["optimizer_steps"] == res[1]["optimizer_steps"] == 4
+    assert res[0]["accuracy"] == res[1]["accuracy"]
+    assert os.path.exists(tmp_path / "model.safetensors") and os.path.exists(tmp_path / "training_state.pt")

@@ -1,0 +1,333 @@
+"""CPU-side plumbing: config, samplers, collation, optimizer, schedule, metric, arena, checkpoints, HF parity."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pytorch_distributed_training_amd as pdt  # noqa: F401
+from pytorch_distributed_training_amd.config import TrainConfig, parse_config, str2bool
+from pytorch_distributed_training_amd.data import PadCollator, ShardedBatchSampler, SyntheticPairDataset
+from pytorch_distributed_training_amd.data.samplers import DistributedShardSampler
+from pytorch_distributed_training_amd.models.bert import build_model
+from pytorch_distributed_training_amd.ops.arena import ParamArena
+from pytorch_distributed_training_amd.optim import FusedAdamW, HFAdamW, LinearWarmupSchedule, LossScaler
+
+
+# ------------------------------------------------------------------------------------------- config
+def test_bool_flags_parse_properly_and_keep_reference_spelling():
+    assert parse_config(["--fp16=True"]).fp16 is True
+    assert parse_config(["--fp16=False"]).fp16 is False  # the reference's type=bool would give True
+    assert parse_config(["--fp16"]).fp16 is True
+    assert parse_config([]).fp16 is False
+    assert parse_config(["--cpu", "yes"]).cpu is True
+    with pytest.raises(Exception):
+        str2bool("maybe")
+
+
+def test_reference_defaults_and_accumulation_policy():
+    c = TrainConfig()
+    assert (c.lr, c.num_epochs, c.correct_bias, c.seed, c.batch_size) == (2e-5, 3, True, 42, 96)
+    assert c.accumulation() == (12, 8)
+    assert TrainConfig(batch_size=8).accumulation() == (1, 8)
+    assert TrainConfig(batch_size=20).accumulation() == (2, 8)
+
+
+# ------------------------------------------------------------------------------------------- samplers
+@pytest.mark.parametrize("n,bs,w", [(100, 8, 2), (3668, 8, 2), (408, 32, 2), (17, 4, 4), (64, 8, 8), (5, 4, 4), (33, 8, 3)])
+def test_sharded_batch_sampler_matches_accelerate(n, bs, w):
+    from accelerate.data_loader import BatchSamplerShard
+    from torch.utils.data import BatchSampler, SequentialSampler
+
+    for drop_last in (False, True):
+        base = BatchSampler(SequentialSampler(range(n)), bs, drop_last)
+        for r in range(w):
+            ours = ShardedBatchSampler(base, w, r)
+            ref = BatchSamplerShard(base, w, r)
+            assert list(ours) == list(ref), (n, bs, w, r, drop_last)
+            assert len(ours) == len(ref)
+
+
+@pytest.mark.parametrize("n,w", [(408, 2), (3668, 2), (10, 4), (7, 8)])
+def test_distributed_shard_sampler_matches_torch(n, w):
+    from torch.utils.data.distributed import DistributedSampler
+
+    data = list(range(n))
+    for r in range(w):
+        for shuffle in (True, False):
+            ours = DistributedShardSampler(data, w, r, shuffle=shuffle, seed=3)
+            ref = DistributedSampler(data, w, r, shuffle=shuffle, seed=3)
+            for epoch in (0, 1, 5):
+                ours.set_epoch(epoch); ref.set_epoch(epoch)
+                assert list(ours) == list(ref)
+            assert len(ours) == len(ref)
+
+
+def test_sharded_epoch_covers_dataset_and_wraps_evenly():
+    n, bs, w = 3668, 8, 2
+    from torch.utils.data import BatchSampler, SequentialSampler
+
+    base = BatchSampler(SequentialSampler(range(n)), bs, False)
+    seen, lens = [], []
+    for r in range(w):
+        b = list(ShardedBatchSampler(base, w, r))
+        lens.append(len(b))
+        assert all(len(x) == bs for x in b)
+        seen += [i for x in b for i in x]
+    assert lens == [230, 230]  # 459 batches -> 230 per rank, the schedule length the reference relies on
+    assert set(seen) == set(range(n))
+
+
+def test_collator_pads_longest_and_fixed():
+    ds = SyntheticPairDataset(8, vocab_size=2000, min_len=3, max_len=9, seed=0)
+    ex = [ds[i] for i in range(8)]
+    b = PadCollator()(ex)
+    L = max(len(e["input_ids"]) for e in ex)
+    assert b["input_ids"].shape == (8, L) and b["labels"].shape == (8,)
+    for i, e in enumerate(ex):
+        n = len(e["input_ids"])
+        assert b["attention_mask"][i].sum() == n and (b["input_ids"][i, n:] == 0).all()
+        assert b["input_ids"][i, 0] == 101 and b["token_type_ids"][i, n - 1] == 1
+    b = PadCollator(padding="max_length", max_length=128)(ex)
+    assert b["input_ids"].shape == (8, 128)
+    b = PadCollator(pad_to_multiple_of=16)(ex)
+    assert b["input_ids"].shape[1] % 16 == 0
+    assert b.to("cpu") is b
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def _hf_formula(p, g, m, v, t, lr, b1, b2, eps, wd, correct):
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    ss = lr * (math.sqrt(1 - b2 ** t) / (1 - b1 ** t) if correct else 1.0)
+    p = p - ss * m / (v.sqrt() + eps)
+    if wd:
+        p = p - lr * wd * p
+    return p, m, v
+
+
+@pytest.mark.parametrize("correct_bias", [True, False])
+def test_hf_adamw_and_fused_cpu_follow_the_hf_update(correct_bias):
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(7, 5)
+    ref = [p.detach().clone().double() for p in lin.parameters()]
+    ms = [torch.zeros_like(r) for r in ref]; vs = [torch.zeros_like(r) for r in ref]
+    lin2 = torch.nn.Linear(7, 5); lin2.load_state_dict(lin.state_dict())
+    opt = HFAdamW(lin.parameters(), lr=1e-2, weight_decay=0.1, correct_bias=correct_bias)
+    arena = ParamArena(lin2, torch.device("cpu"))
+    fused = FusedAdamW(arena, lr=1e-2, weight_decay=0.1, correct_bias=correct_bias)
+    for t in range(1, 5):
+        x = torch.randn(3, 7)
+        for mod in (lin, lin2):
+            mod.zero_grad() if mod is lin else arena.zero_grad()
+            mod(x).pow(2).sum().backward()
+        gs = [p.grad.detach().clone().double() for p in lin.parameters()]
+        opt.step(); fused.step()
+        for i in range(len(ref)):
+            ref[i], ms[i], vs[i] = _hf_formula(ref[i], gs[i], ms[i], vs[i], t, 1e-2, 0.9, 0.999, 1e-6, 0.1, correct_bias)
+        for p, p2, r in zip(lin.parameters(), lin2.parameters(), ref):
+            torch.testing.assert_close(p.double(), r, rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(p2.double(), r, rtol=1e-5, atol=1e-7)
+
+
+def test_loss_scaler_skip_and_growth_on_cpu():
+    lin = torch.nn.Linear(4, 4)
+    arena = ParamArena(lin, torch.device("cpu"))
+    sc = LossScaler("cpu", enabled=True, init_scale=8.0, growth_interval=2)
+    opt = FusedAdamW(arena, lr=0.1, scaler=sc)
+    before = arena.master.clone()
+    arena.grad.fill_(float("inf"))
+    opt.step()
+    assert torch.equal(arena.master, before) and sc.get_scale() == 4.0 and sc.last_step_skipped()
+    assert int(opt.step_count) == 0
+    arena.grad.fill_(4.0)  # = 1.0 after un-scaling
+    opt.step(); opt.step()
+    assert sc.get_scale() == 8.0 and int(opt.step_count) == 2 and not sc.last_step_skipped()
+    assert not torch.equal(arena.master, before)
+
+
+def test_linear_schedule_matches_transformers():
+    from transformers import get_linear_schedule_with_warmup as hf_sched
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    o1 = torch.optim.SGD([p], lr=2e-5); o2 = HFAdamW([p], lr=2e-5)
+    s1 = hf_sched(o1, 100, 690); s2 = LinearWarmupSchedule(o2, 100, 690)
+    for _ in range(700):
+        assert abs(s1.get_last_lr()[0] - s2.get_last_lr()[0]) < 1e-12
+        assert abs(o1.param_groups[0]["lr"] - o2.param_groups[0]["lr"]) < 1e-12
+        o1.step(); s1.step(); s2.step()
+
+
+# ------------------------------------------------------------------------------------------- metric
+def test_mrpc_metric_matches_sklearn():
+    from sklearn.metrics import accuracy_score, f1_score
+
+    from pytorch_distributed_training_amd.metrics import load_metric
+
+    g = torch.Generator().manual_seed(0)
+    m = load_metric("glue", "mrpc")
+    P, R = [], []
+    for _ in range(5):
+        p, r = torch.randint(0, 2, (32,), generator=g), torch.randint(0, 2, (32,), generator=g)
+        m.add_batch(predictions=p, references=r)
+        P += p.tolist(); R += r.tolist()
+    out = m.compute()
+    assert abs(out["accuracy"] - accuracy_score(R, P)) < 1e-12 and abs(out["f1"] - f1_score(R, P)) < 1e-12
+    m.add_batch(predictions=torch.tensor([1, 1, 0, 0]), references=torch.tensor([1, 0, 0, 1]), valid=2)
+    assert m.compute()["accuracy"] == 0.5
+
+
+# ------------------------------------------------------------------------------------------- arena
+def test_arena_layout_views_and_buckets():
+    model = build_model("bert-tiny")
+    names = [n for n, _ in model.named_parameters()]
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    arena = ParamArena(model, torch.device("cpu"), min_bucket_elems=1 << 16)
+    # parameters are views of the arena with unchanged values and HF names
+    assert [n for n, _ in model.named_parameters()] == names
+    for n, p in model.named_parameters():
+        assert torch.equal(p, before[n])
+        o, k = arena.offsets[n]
+        assert p.data_ptr() == arena.master[o:].data_ptr() and p.grad.data_ptr() == arena.grad[o:].data_ptr()
+    # reverse forward order: head first, embeddings last; Q/K/V adjacent
+    assert arena.segments[0].name == "head" and arena.segments[-1].name == "embeddings"
+    pre = "bert.encoder.layer.0.attention.self."
+    assert arena.adjacent([pre + "query.weight", pre + "key.weight", pre + "value.weight"])
+    assert arena.adjacent([pre + "query.bias", pre + "key.bias", pre + "value.bias"])
+    assert arena.bucket_bounds[0] == 0 and arena.bucket_bounds[-1] == arena.numel
+    assert sum(arena.bucket_segments) == len(arena.segments)
+    assert all(b % 64 == 0 for b in arena.bucket_bounds)
+    # autograd accumulates into the arena
+    ids = torch.randint(0, 512, (2, 8))
+    model(input_ids=ids, labels=torch.tensor([0, 1])).loss.backward()
+    assert arena.grad.abs().sum() > 0
+    arena.zero_grad()
+    assert arena.grad.abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------------------- HF parity
+def _hf_bert(cfg):
+    from transformers import BertConfig, BertForSequenceClassification
+
+    hc = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                    num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                    max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, num_labels=cfg.num_labels)
+    hc._attn_implementation = "eager"
+    return BertForSequenceClassification(hc).eval()
+
+
+def test_bert_matches_transformers_names_logits_and_grads():
+    ours = build_model("bert-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0).eval()
+    hf = _hf_bert(ours.config)
+    assert set(dict(ours.named_parameters())) == set(dict(hf.named_parameters()))
+    hf.load_state_dict(ours.state_dict(), strict=False)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(1, 512, (3, 20), generator=g)
+    mask = torch.ones(3, 20, dtype=torch.long); mask[1, 12:] = 0; mask[2, 5:] = 0
+    types = torch.zeros(3, 20, dtype=torch.long); types[:, 10:] = 1
+    labels = torch.tensor([0, 1, 1])
+    a = ours(input_ids=ids, attention_mask=mask, token_type_ids=types, labels=labels, output_hidden_states=True)
+    b = hf(input_ids=ids, attention_mask=mask, token_type_ids=types, labels=labels, output_hidden_states=True)
+    torch.testing.assert_close(a.logits, b.logits, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.loss, b.loss, rtol=1e-5, atol=1e-6)
+    assert len(a.hidden_states) == len(b.hidden_states) == 3
+    valid = mask.bool()
+    torch.testing.assert_close(a.hidden_states[-1][valid], b.hidden_states[-1][valid], rtol=1e-4, atol=1e-5)
+    a.loss.backward(); b.loss.backward()
+    hfp = dict(hf.named_parameters())
+    for n, p in ours.named_parameters():
+        torch.testing.assert_close(p.grad, hfp[n].grad, rtol=1e-3, atol=1e-6, msg=n)
+
+
+def test_roberta_matches_transformers():
+    from transformers import RobertaConfig, RobertaForSequenceClassification
+
+    ours = build_model("roberta-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0).eval()
+    c = ours.config
+    hc = RobertaConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers,
+                       num_attention_heads=c.num_attention_heads, intermediate_size=c.intermediate_size,
+                       max_position_embeddings=c.max_position_embeddings, type_vocab_size=c.type_vocab_size,
+                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=c.layer_norm_eps,
+                       pad_token_id=c.pad_token_id, num_labels=2)
+    hc._attn_implementation = "eager"
+    hf = RobertaForSequenceClassification(hc).eval()
+    assert set(dict(ours.named_parameters())) == set(dict(hf.named_parameters()))
+    hf.load_state_dict(ours.state_dict(), strict=False)
+    ids = torch.randint(3, 512, (2, 16)); ids[1, 9:] = c.pad_token_id
+    mask = ids.ne(c.pad_token_id).long()
+    a = ours(input_ids=ids, attention_mask=mask, labels=torch.tensor([1, 0]))
+    b = hf(input_ids=ids, attention_mask=mask, labels=torch.tensor([1, 0]))
+    torch.testing.assert_close(a.logits, b.logits, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.loss, b.loss, rtol=1e-5, atol=1e-6)
+
+
+def test_piecemeal_access_used_by_model_parallel_script():
+    m = build_model("bert-tiny").eval()
+    ids = torch.randint(1, 512, (2, 12)); mask = torch.ones(2, 12, dtype=torch.long); mask[1, 8:] = 0
+    emb = m.get_input_embeddings()(ids)
+    out = m(inputs_embeds=emb, attention_mask=mask, token_type_ids=torch.zeros_like(ids), output_hidden_states=True)
+    ref = m(input_ids=ids, attention_mask=mask, token_type_ids=torch.zeros_like(ids), output_hidden_states=True)
+    torch.testing.assert_close(out.hidden_states[-1], ref.hidden_states[-1])
+    ext = m.get_extended_attention_mask(mask, ids.shape, ids.device)
+    assert ext.shape == (2, 1, 1, 12) and ext[1, 0, 0, -1] == torch.finfo(torch.float32).min and ext[0].abs().sum() == 0
+    seq = m.bert.encoder(hidden_states=ref.hidden_states[0], attention_mask=ext)[0]
+    torch.testing.assert_close(seq, ref.hidden_states[-1])
+    logits = m.classifier(m.dropout(m.bert.pooler(seq)))
+    torch.testing.assert_close(logits, ref.logits)
+    assert m.num_labels == 2
+
+
+# ------------------------------------------------------------------------------------------- checkpoints
+def test_checkpoint_roundtrip_and_loads_into_transformers(tmp_path):
+    from transformers import BertForSequenceClassification
+
+    from pytorch_distributed_training_amd import checkpoint as ck
+
+    m = build_model("bert-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0).eval()
+    d = str(tmp_path / "ckpt")
+    ck.save_pretrained(m, d)
+    assert os.path.exists(os.path.join(d, "config.json")) and os.path.exists(os.path.join(d, "model.safetensors"))
+    m2 = ck.load_pretrained(d).eval()
+    ids = torch.randint(1, 512, (2, 10))
+    torch.testing.assert_close(m(input_ids=ids).logits, m2(input_ids=ids).logits)
+    hf = BertForSequenceClassification.from_pretrained(d, attn_implementation="eager").eval()
+    torch.testing.assert_close(m(input_ids=ids).logits, hf(input_ids=ids).logits, rtol=1e-4, atol=1e-5)
+    # and the other direction: a directory written by transformers loads here
+    d2 = str(tmp_path / "hf")
+    hf.save_pretrained(d2)
+    m3 = ck.load_pretrained(d2).eval()
+    torch.testing.assert_close(m3(input_ids=ids).logits, hf(input_ids=ids).logits, rtol=1e-4, atol=1e-5)
+
+
+def test_training_state_resume_is_exact(tmp_path):
+    from pytorch_distributed_training_amd import checkpoint as ck
+    from pytorch_distributed_training_amd.optim import get_linear_schedule_with_warmup
+
+    def make():
+        torch.manual_seed(0)
+        m = build_model("bert-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        a = ParamArena(m, torch.device("cpu"))
+        o = FusedAdamW(a, lr=1e-3)
+        s = get_linear_schedule_with_warmup(o, 2, 20)
+        return m, a, o, s
+
+    def step(m, o, s, i):
+        g = torch.Generator().manual_seed(i)
+        ids = torch.randint(1, 512, (4, 10), generator=g)
+        loss = m(input_ids=ids, labels=torch.randint(0, 2, (4,), generator=g)).loss
+        loss.backward(); o.step(); s.step(); o.zero_grad()
+        return loss.item()
+
+    m, a, o, s = make()
+    for i in range(3):
+        step(m, o, s, i)
+    ck.save_training_state(str(tmp_path), m, o, s, {"epoch": 1, "global_step": 3})
+    cont = [step(m, o, s, i) for i in range(3, 6)]
+    m2, a2, o2, s2 = make()
+    extra = ck.load_training_state(str(tmp_path), m2, o2, s2)
+    assert extra == {"epoch": 1, "global_step": 3} and ck.has_checkpoint(str(tmp_path))
+    again = [step(m2, o2, s2, i) for i in range(3, 6)]
+    assert cont == again
+    assert torch.equal(a.master, a2.master)
