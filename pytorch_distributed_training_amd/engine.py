@@ -47,8 +47,8 @@ class EngineOptimizer:
     def param_groups(self):
         return self.optimizer.param_groups
 
-    def step(self):
-        self.optimizer.step()
+    def step(self, **kw):
+        self.optimizer.step(**kw)
 
     def zero_grad(self, set_to_none: bool = False):
         self.optimizer.zero_grad()

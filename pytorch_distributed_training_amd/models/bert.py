@@ -294,8 +294,14 @@ class BertModel(nn.Module):
         return self.embeddings.word_embeddings
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, inputs_embeds=None,
-                output_hidden_states=False, rng=None):
-        x = self.embeddings(input_ids, token_type_ids, inputs_embeds, rng)
+                output_hidden_states=False, rng=None, hidden_states=None):
+        """`hidden_states`: input of a pipeline stage that has no embeddings (output of the previous stage)."""
+        if self.embeddings is None:
+            if hidden_states is None:
+                raise ValueError("this stage has no embeddings: pass hidden_states= from the previous stage")
+            x = hidden_states
+        else:
+            x = self.embeddings(input_ids, token_type_ids, inputs_embeds, rng)
         b, s = x.shape[:2]
         mask = MaskInfo(attention_mask, b, s, x.device)
         last, all_h = self.encoder(x, mask_info=mask, output_hidden_states=output_hidden_states, rng=rng)
@@ -424,11 +430,16 @@ class BertForSequenceClassification(_ClassifierBase):
         return SequenceClassifierOutput(loss=loss, logits=logits)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
-                inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, **unused):
+                inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
+                **unused):
         self._begin_forward()
-        out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng)
+        out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
+                        hidden_states)
+        if not self.with_head:  # a pipeline stage that ends inside the encoder stack
+            return out
         res = self.head(out.last_hidden_state, labels)
         res.hidden_states = out.hidden_states
+        res.last_hidden_state = out.last_hidden_state
         return res
 
 
@@ -479,17 +490,23 @@ class RobertaForSequenceClassification(_ClassifierBase):
         return SequenceClassifierOutput(loss=loss, logits=logits)
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
-                inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, **unused):
+                inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
+                **unused):
         self._begin_forward()
-        out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng)
+        out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
+                        hidden_states)
+        if not self.with_head:  # a pipeline stage that ends inside the encoder stack
+            return out
         res = self.head(out.last_hidden_state, labels)
         res.hidden_states = out.hidden_states
+        res.last_hidden_state = out.last_hidden_state
         return res
 
 
-def build_model(name_or_cfg, **overrides) -> _ClassifierBase:
+def build_model(name_or_cfg, layer_range=None, with_embeddings=True, with_head=True, **overrides) -> _ClassifierBase:
     """``AutoModelForSequenceClassification``-style factory (random init; see
-    ``checkpoint.load_pretrained`` for weights on disk)."""
+    ``checkpoint.load_pretrained`` for weights on disk).  `layer_range` / `with_embeddings` / `with_head`
+    build one stage of a layer-split model; parameter names keep the GLOBAL layer indices."""
     cfg = name_or_cfg if isinstance(name_or_cfg, EncoderConfig) else preset(name_or_cfg, **overrides)
     cls = RobertaForSequenceClassification if cfg.model_type == "roberta" else BertForSequenceClassification
-    return cls(cfg)
+    return cls(cfg, layer_range=layer_range, with_embeddings=with_embeddings, with_head=with_head)

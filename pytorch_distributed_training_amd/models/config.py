@@ -115,6 +115,11 @@ _PRESETS: Dict[str, EncoderConfig] = {
         vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
         max_position_embeddings=128,
     ),
+    # the same tiny encoder without dropout: deterministic loss curves for parity tests
+    "bert-tiny-nodrop": EncoderConfig(
+        vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+        max_position_embeddings=128, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+    ),
     "roberta-tiny": EncoderConfig(
         model_type="roberta", vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
         intermediate_size=512, max_position_embeddings=130, type_vocab_size=1, layer_norm_eps=1e-5,

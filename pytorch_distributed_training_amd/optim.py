@@ -83,15 +83,23 @@ class FusedAdamW:
         self.arena.zero_grad()
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, overflow_group=None) -> None:
+        """`overflow_group`: ranks that must agree on skipping the step (the stages of one pipeline replica:
+        an inf on one stage's gradients has to skip the update on all of them)."""
         a = self.arena
         if a.master.is_cuda:
             from .ops import native
 
             C = native()
+            check = self.scaler.enabled
+            if check and overflow_group is not None:
+                import torch.distributed as dist
+
+                C.grad_check(a.grad, self.scaler.state)
+                dist.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=overflow_group)
+                check = False
             C.adamw_step(a.master, self.m, self.v, a.grad, a.p16, self.lr, self.step_count, self.scaler.state,
-                         self.betas[0], self.betas[1], self.eps, self.weight_decay, self.correct_bias,
-                         self.scaler.enabled)
+                         self.betas[0], self.betas[1], self.eps, self.weight_decay, self.correct_bias, check)
             C.scaler_update(self.scaler.state, self.step_count, self.scaler.growth_factor,
                             self.scaler.backoff_factor, self.scaler.growth_interval, self.scaler.dynamic)
         else:

@@ -114,6 +114,7 @@ class DataParallel(nn.Module):
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.pg)
         self.require_sync = True
+        self.auto_arm = True  # forward() arms the reducer; a pipeline driver arms it itself before the last backward
         self._armed = False
         self._callback_queued = False
         runtime = getattr(module, "runtime", None)
@@ -178,7 +179,7 @@ class DataParallel(nn.Module):
             self.require_sync = old
 
     def forward(self, *args, **kwargs):
-        if self.training and torch.is_grad_enabled():
+        if self.auto_arm and self.training and torch.is_grad_enabled():
             self.prepare_backward()
         return self.module(*args, **kwargs)
 

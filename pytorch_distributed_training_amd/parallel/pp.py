@@ -1,0 +1,273 @@
+"""2-stage layer-split model parallelism, micro-batched (1F1B), composed with data parallelism.
+
+The reference's model-parallel idea - stage 1 = embeddings + a stack of layers on one device, the hidden
+states and the mask hop to a second device, stage 2 = the rest of the stack + pooler + classifier + loss
+(``ConcatBert``, /root/reference/test_model_parallelism.py:40-89) - is done here with one process per GPU:
+activations travel forward and their gradients backward over send/recv of the pipeline group ("nccl" =
+RCCL over the direct xGMI link of the GPU pair; gloo on CPU), a batch is cut into micro-batches so that
+both stages work at the same time (bubble fraction 1/(m+1) for two stages), and each stage is additionally
+data-parallel across replicas through its own bucket reducer.  Only hidden states are exchanged: both stage
+ranks of a replica read the same batches, so the attention mask and the labels never cross the link.
+
+Send/recv pairs that must progress together are issued as ONE batched P2P group
+(``send next activation`` + ``recv previous gradient``), otherwise the two ranks would wait on each other's
+matching call.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .dp import DataParallel
+from .groups import ParallelMesh
+
+
+def split_layers(num_layers: int, stages: int) -> List[Tuple[int, int]]:
+    """Contiguous layer ranges, as even as possible (earlier stages get the remainder)."""
+    base, rem = divmod(num_layers, stages)
+    out, lo = [], 0
+    for s in range(stages):
+        hi = lo + base + (1 if s < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def build_stage(model_cfg, stage: int, stages: int, full_state: Optional[Dict[str, torch.Tensor]] = None,
+                seed: Optional[int] = None) -> nn.Module:
+    """Module of one pipeline stage.  Its initial weights are the corresponding slice of the FULL model
+    built from `seed` (or of `full_state`), so a pipelined run starts from the same point as a
+    single-process run - a precondition for matching loss curves."""
+    from ..models.bert import build_model
+
+    lo, hi = split_layers(model_cfg.num_hidden_layers, stages)[stage]
+    if full_state is None:
+        if seed is not None:
+            torch.manual_seed(seed)
+        full_state = build_model(model_cfg).state_dict()
+    part = build_model(model_cfg, layer_range=(lo, hi), with_embeddings=stage == 0, with_head=stage == stages - 1)
+    own = part.state_dict()
+    missing = [k for k in own if k not in full_state]
+    if missing:
+        raise KeyError(f"stage {stage}: parameters missing from the full state dict: {missing[:4]}")
+    part.load_state_dict({k: full_state[k] for k in own})
+    return part
+
+
+def _split_batch(batch: Dict[str, torch.Tensor], m: int) -> List[Dict[str, torch.Tensor]]:
+    n = next(iter(batch.values())).shape[0]
+    m = max(1, min(m, n))
+    bounds = [round(i * n / m) for i in range(m + 1)]
+    return [{k: v[bounds[i]:bounds[i + 1]] for k, v in batch.items()} for i in range(m)]
+
+
+def _p2p(ops) -> None:
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
+class PipelineStage:
+    """Driver of one rank of a 2-stage pipeline replica."""
+
+    def __init__(self, module: nn.Module, mesh: ParallelMesh, engine, micro_batches: int = 4):
+        if mesh.pp != 2:
+            raise ValueError("the pipeline schedule is written for exactly 2 stages")
+        self.module, self.mesh, self.engine, self.m = module, mesh, engine, micro_batches
+        self.dp = module if isinstance(module, DataParallel) else None
+        if self.dp is not None:
+            self.dp.auto_arm = False
+        inner = module.module if self.dp is not None else module
+        self.inner = inner
+        arena = getattr(inner, "arena", None)
+        self.act_dtype = arena.p16.dtype if (arena is not None and arena.p16 is not None) else torch.float32
+        self.hidden = inner.config.hidden_size
+        self.first, self.last = mesh.is_first_stage, mesh.is_last_stage
+        self.prev, self.next = mesh.peer(0), mesh.peer(1)
+        self.timers = {"p2p_wait_s": 0.0}
+
+    # -- communication -------------------------------------------------------------------------------
+    def _buf(self, chunk: Dict[str, torch.Tensor]) -> torch.Tensor:
+        b, s = chunk["attention_mask"].shape
+        return torch.empty(b, s, self.hidden, dtype=self.act_dtype, device=self.engine.device)
+
+    def _send(self, t: torch.Tensor, dst: int) -> None:
+        _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)])
+
+    def _recv(self, buf: torch.Tensor, src: int) -> torch.Tensor:
+        _p2p([dist.P2POp(dist.irecv, buf, src)])
+        return buf
+
+    def _send_recv(self, t: torch.Tensor, buf: torch.Tensor, peer: int) -> torch.Tensor:
+        _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)])
+        return buf
+
+    def _arm(self) -> None:
+        if self.dp is not None:
+            self.dp.prepare_backward()
+
+    # -- one optimizer step worth of micro-batches -----------------------------------------------------
+    def train_step(self, batch: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
+        """Forward + backward of `batch` cut into micro-batches.  Returns the batch-mean loss on the last
+        stage (None on the first).  Gradients accumulate in the arena; the data-parallel all-reduce is armed
+        only for the final micro-batch's backward."""
+        chunks = _split_batch(batch, self.m)
+        m, total = len(chunks), next(iter(batch.values())).shape[0]
+        self.module.train()
+        if self.first:
+            outs: List[Optional[torch.Tensor]] = []
+            out = self._fwd_first(chunks[0])
+            self._send(out.detach(), self.next)
+            outs.append(out)
+            for i in range(m - 1):
+                nxt = self._fwd_first(chunks[i + 1])
+                outs.append(nxt)
+                g = self._send_recv(nxt.detach(), self._buf(chunks[i]), self.next)
+                outs[i].backward(g)
+                outs[i] = None
+            g = self._recv(self._buf(chunks[m - 1]), self.next)
+            self._arm()
+            outs[m - 1].backward(g)
+            return None
+        loss_sum = None
+        act = self._recv(self._buf(chunks[0]), self.prev)
+        for i in range(m):
+            act.requires_grad_()
+            c = chunks[i]
+            out = self.module(hidden_states=act, attention_mask=c["attention_mask"], labels=c["labels"])
+            loss = out.loss * (c["labels"].shape[0] / total)  # exact batch-mean over unequal micro-batches
+            if i == m - 1:
+                self._arm()
+            self.engine.backward(loss)
+            g = act.grad
+            if i < m - 1:
+                act = self._send_recv(g, self._buf(chunks[i + 1]), self.prev)
+            else:
+                self._send(g, self.prev)
+            loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
+        return loss_sum
+
+    def _fwd_first(self, c: Dict[str, torch.Tensor]) -> torch.Tensor:
+        out = self.module(input_ids=c["input_ids"], attention_mask=c["attention_mask"],
+                          token_type_ids=c.get("token_type_ids"))
+        return out.last_hidden_state
+
+    @torch.no_grad()
+    def eval_step(self, batch: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
+        """Forward only; logits on the last stage."""
+        self.module.eval()
+        if self.first:
+            self._send(self._fwd_first(batch), self.next)
+            return None
+        act = self._recv(self._buf(batch), self.prev)
+        return self.module(hidden_states=act, attention_mask=batch["attention_mask"]).logits
+
+    def optimizer_step(self, optimizer, scheduler=None) -> None:
+        optimizer.step(overflow_group=self.mesh.pp_group if self.engine.scaler.enabled else None)
+        if scheduler is not None:
+            scheduler.step()
+        optimizer.zero_grad()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
+    """DP x 2-stage-MP training recipe (see recipes.run_model_parallel)."""
+    from torch.utils.data import DataLoader
+
+    from .. import checkpoint as ckpt
+    from ..engine import Engine
+    from ..metrics import load_metric
+    from ..models.config import preset
+    from ..optim import AdamW, get_linear_schedule_with_warmup
+    from ..recipes import _collator, build_datasets
+    from ..utils.logging import StepLogger
+    from ..utils.seed import set_seed
+
+    if cfg.mp_layout == "towers":
+        from ..models.tribert import run_tower_training
+
+        return run_tower_training(rank, world_size, cfg)
+    from .. import launch
+
+    env, device = launch.init_distributed(cpu=cfg.cpu)
+    print("LOCAL_RANK: ", rank)
+    print("world_size: ", world_size)
+    print("MASTER_ADDR:", os.environ.get("MASTER_ADDR"))
+    print("MASTER_PORT:", os.environ.get("MASTER_PORT"))
+    mesh = ParallelMesh(world_size, rank, pp=2).build_groups()
+    engine = Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed, process_group=mesh.dp_group,
+                    min_bucket_mb=cfg.min_bucket_mb)
+    model_cfg = preset(cfg.model) if not cfg.init_from else ckpt.EncoderConfig.load(cfg.init_from)
+    train_ds, val_ds = build_datasets(cfg, model_cfg)
+    accum, micro_bs = cfg.accumulation()
+    collate = _collator(cfg, model_cfg)
+    # one loader batch = one optimizer step = `accum` pipeline micro-batches
+    train_dl = DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=micro_bs * accum)
+    eval_dl = DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size)
+    set_seed(cfg.seed)
+    full_state = ckpt._read_weights(cfg.init_from) if cfg.init_from else None
+    stage_model = build_stage(model_cfg, mesh.stage, 2, full_state, seed=cfg.seed)
+    print(f"[RANK: {rank}] Initialized model (stage {mesh.stage}, replica {mesh.replica}).")
+    optimizer = AdamW(params=stage_model.parameters(), lr=cfg.lr, correct_bias=cfg.correct_bias)
+    print(f"[RANK: {rank}] Initialized optimizer.")
+    stage_model, optimizer, train_dl, eval_dl = engine.prepare(stage_model, optimizer, train_dl, eval_dl)
+    print(f"[RANK: {rank}] All prepared.")
+    steps_per_epoch = len(train_dl)
+    sched = get_linear_schedule_with_warmup(optimizer, cfg.num_warmup_steps, steps_per_epoch * cfg.num_epochs)
+    pipe = PipelineStage(stage_model, mesh, engine, micro_batches=accum if accum > 1 else cfg.micro_batches)
+    metric = load_metric("glue", "mrpc")
+    log_rank = mesh.is_last_stage and engine.is_main_process
+    logger = StepLogger(log_rank, cfg.log_every, cfg.log_file, samples_per_step=micro_bs * accum * mesh.dp)
+    suffix = f"stage{mesh.stage}"
+    start_epoch, global_step = 0, 0
+    if cfg.output_dir and ckpt.has_checkpoint(cfg.output_dir, suffix):
+        extra = ckpt.load_training_state(cfg.output_dir, stage_model, optimizer, sched, suffix)
+        start_epoch, global_step = int(extra.get("epoch", 0)), int(extra.get("global_step", 0))
+    losses: List[float] = []
+    result: dict = {}
+    t0 = time.perf_counter()
+    done = False
+    for epoch in range(start_epoch, cfg.num_epochs):
+        train_dl.set_epoch(epoch)
+        for batch in train_dl:
+            loss = pipe.train_step(batch)
+            pipe.optimizer_step(optimizer, sched)
+            global_step += 1
+            if loss is not None:
+                record = global_step % cfg.log_every == 0 or bool(cfg.max_steps)
+                if record and mesh.dp > 1:
+                    loss = engine.reduce_mean(loss)  # global-batch loss: mean over the replicas' shards
+                if log_rank and record:
+                    losses.append(float(loss.item()))
+                logger.log_step(global_step, loss, sched.get_last_lr()[0], engine.scaler)
+            if cfg.max_steps and global_step >= cfg.max_steps:
+                done = True
+                break
+        seen = 0
+        for batch in eval_dl:
+            logits = pipe.eval_step(batch)
+            if logits is not None:
+                preds, refs = engine.gather(logits.argmax(dim=-1)), engine.gather(batch["labels"])
+                valid = max(0, min(preds.shape[0], len(val_ds) - seen))
+                seen += preds.shape[0]
+                metric.add_batch(predictions=preds, references=refs, valid=valid)
+        result = metric.compute() if mesh.is_last_stage else {}
+        logger.log_epoch(epoch, result)
+        if cfg.output_dir and engine.is_main_process:
+            ckpt.save_training_state(cfg.output_dir, stage_model, optimizer, sched,
+                                     {"epoch": epoch + 1, "global_step": global_step}, suffix)
+        dist.barrier()
+        if done:
+            break
+    # every rank returns the metric of the last stage of replica 0
+    box = [result if (mesh.is_last_stage and mesh.replica == 0) else None]
+    dist.broadcast_object_list(box, src=ParallelMesh(world_size, 0, 2).peer(1))
+    out = dict(box[0] or {})
+    out.update({"optimizer_steps": global_step, "wall_s": time.perf_counter() - t0, "losses": losses,
+                "stage": mesh.stage, "replica": mesh.replica})
+    logger.close()
+    return out

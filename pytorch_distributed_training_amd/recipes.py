@@ -52,7 +52,10 @@ def build_datasets(cfg: TrainConfig, model_cfg):
 
         return load_mrpc_tsv(cfg.data_dir, cfg.vocab_file, max_length=model_cfg.max_position_embeddings)
     roberta = model_cfg.model_type == "roberta"
-    max_len = 64 if not cfg.max_length else max(4, min(64, (cfg.max_length - 3) // 2))
+    # truncation to the model's maximum length, as the reference's tokenizer call does (truncation=True)
+    room = model_cfg.max_position_embeddings - (model_cfg.pad_token_id + 1 if roberta else 0)
+    limit = min(room, cfg.max_length) if cfg.max_length else room
+    max_len = max(4, min(64, (limit - 3) // 2))
     train = SyntheticPairDataset(cfg.train_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed, roberta=roberta)
     val = SyntheticPairDataset(cfg.eval_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed + 1, roberta=roberta)
     return train, val

@@ -146,3 +146,47 @@ def dp_recipe(rank, world, tmp):
     cfg = TrainConfig(model="bert-tiny", cpu=True, train_examples=48, eval_examples=20, num_epochs=2, batch_size=16,
                       lr=1e-3, num_warmup_steps=2, log_every=100, output_dir=tmp if rank == 0 else tmp)
     return run_data_parallel(cfg)
+
+
+def pipeline_recipe(rank, world, micro_bs, accum):
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.recipes import run_model_parallel
+
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=64, eval_examples=16, num_epochs=2,
+                      batch_size=micro_bs * accum, max_gpu_batch_size=micro_bs, lr=2e-3, num_warmup_steps=1,
+                      log_every=1, max_steps=6, seed=5)
+    return run_model_parallel(rank, world, cfg)
+
+
+def single_process_reference(batch_size, steps=6):
+    """Loss curve of ONE process on the whole global batch, same seed / data order / init as the pipeline runs."""
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.models.config import preset
+    from pytorch_distributed_training_amd.optim import get_linear_schedule_with_warmup
+    from pytorch_distributed_training_amd.recipes import _collator, build_datasets
+    from pytorch_distributed_training_amd.utils.seed import set_seed
+
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=64, eval_examples=16, num_epochs=2,
+                      batch_size=batch_size, lr=2e-3, num_warmup_steps=1, seed=5)
+    eng = Engine(cpu=True, seed=5)
+    mc = preset(cfg.model)
+    train_ds, _ = build_datasets(cfg, mc)
+    dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=batch_size)
+    set_seed(5)
+    torch.manual_seed(5)
+    model = build_model(mc)
+    opt = AdamW(params=model.parameters(), lr=2e-3)
+    model, opt, dl = eng.prepare(model, opt, dl)
+    sched = get_linear_schedule_with_warmup(opt, 1, len(dl) * 2)
+    losses = []
+    model.train()
+    for epoch in range(2):
+        dl.set_epoch(epoch)
+        for batch in dl:
+            loss = model(**batch).loss
+            eng.backward(loss)
+            opt.step(); sched.step(); opt.zero_grad()
+            losses.append(loss.item())
+            if len(losses) >= steps:
+                return losses
+    return losses
