@@ -328,7 +328,7 @@ class _ClassifierBase(nn.Module):
 
         return bert_segments(self, prefix)
 
-    def enable_native(self, arena, seed: int = 0, prefix: str = "", runtime=None):
+    def enable_native(self, arena, seed: int = 0, prefix: str = "", runtime=None, site_offset: int = 0):
         """Route embeddings / layers / pooler / head through the gfx950 kernels.  `arena` must hold this
         model's parameters with a 16-bit compute copy."""
         from ..ops import fused
@@ -345,9 +345,11 @@ class _ClassifierBase(nn.Module):
         if base.embeddings is not None:
             base.embeddings._native = fused.EmbedNative(arena, bp + "embeddings.", cfg,
                                                         arena.seg_index[f"{prefix}embeddings"], rt)
+            base.embeddings._native.site_offset = site_offset
         for lyr in base.encoder.layers():
             lyr._native = fused.LayerNative(arena, f"{bp}encoder.layer.{lyr.index}.", cfg,
                                             arena.seg_index[f"{prefix}layer{lyr.index}"], rt)
+            lyr._native.site_offset = site_offset
         if getattr(self, "with_head", False):
             self._enable_native_head(arena, rt, prefix, arena.seg_index[f"{prefix}head"])
         return rt

@@ -1,0 +1,315 @@
+"""The multi-encoder model-parallel modules of the reference, on this framework.
+
+* :class:`TriBert` (/root/reference/test_model_parallelism.py:92-163): three BERT classifiers; the word
+  embedding, pooler and classifier of tower 1 are shared; the three encoders run on the same
+  ``inputs_embeds``, their last hidden states are averaged, then pooler -> dropout -> classifier -> CE.
+  Towers 2/3 keep (unused, gradient-free) embeddings / poolers / classifiers exactly like the reference,
+  which is why it needs ``find_unused_parameters=True`` - here unused arena slices simply stay zero.
+  Only token 0 of the averaged hidden states reaches the pooler, so the mean is taken on ``[B, H]``.
+* :class:`ConcatBert` (:40-89, unused there): stage 1 = all of ``bert_1``, stage 2 = ``bert_2``'s encoder
+  stack + pooler + dropout + classifier + CE, with the additive mask built by
+  ``get_extended_attention_mask``.  The pipeline of ``parallel/pp.py`` is the multi-process form of it.
+* :func:`run_tower_training`: TriBert with the towers spread over the two ranks of a replica (tower 1 +
+  shared parts on the first rank, towers 2 and 3 on the second - the reference's 1:2 placement), composed
+  with data parallelism across replicas.  The embedding output travels once (the reference copies it twice),
+  and only the token-0 rows come back.
+
+Inside one process every tower lives on that process's GPU; the reference's ``first_device`` /
+``second_device`` arguments are accepted and honoured on the PyTorch path (fp32), where a plain
+``Tensor.to`` moves activations as in the reference.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .bert import SequenceClassifierOutput, build_model
+
+
+class TriBert(nn.Module):
+    def __init__(self, bert_1, bert_2, bert_3, first_device=None, second_device=None):
+        super().__init__()
+        self.first_device = torch.device(first_device) if first_device is not None else None
+        self.second_device = torch.device(second_device) if second_device is not None else None
+        self.bert_1, self.bert_2, self.bert_3 = bert_1, bert_2, bert_3
+        if self.first_device is not None:
+            self.bert_1.to(self.first_device)
+        if self.second_device is not None:
+            self.bert_2.to(self.second_device)
+            self.bert_3.to(self.second_device)
+        self.config = bert_1.config
+        self.num_labels = bert_1.num_labels
+        self.arena = None
+        self.runtime = None
+        self.verbose = False
+
+    # -- arena / native plumbing -----------------------------------------------------------------------
+    def arena_segments(self):
+        segs, heads = [], []
+        for k, b in enumerate((self.bert_1, self.bert_2, self.bert_3), 1):
+            for s in b.arena_segments(prefix=f"bert_{k}."):
+                (heads if s.name.endswith("head") else segs).append(s)
+        return segs + list(reversed(heads))  # tower 1's (the used) head completes first in backward
+
+    def enable_native(self, arena, seed: int = 0):
+        from ..ops import fused
+
+        rt = fused.NativeRuntime(arena, seed)
+        for k, b in enumerate((self.bert_1, self.bert_2, self.bert_3), 1):
+            b.enable_native(arena, prefix=f"bert_{k}.", runtime=rt, site_offset=1024 * k)
+        self.arena, self.runtime = arena, rt
+        return rt
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def _tower(self, bert, inputs_embeds, attention_mask, token_type_ids, device):
+        if device is not None and inputs_embeds.device != device:
+            inputs_embeds, attention_mask, token_type_ids = (t.to(device) for t in (inputs_embeds, attention_mask, token_type_ids))
+        return bert.base_model(inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                               token_type_ids=token_type_ids).last_hidden_state
+
+    def forward(self, **kwargs):
+        input_ids = kwargs.pop("input_ids")
+        attention_mask = kwargs.pop("attention_mask")
+        token_type_ids = kwargs.pop("token_type_ids")
+        labels = kwargs.pop("labels", None)
+        if self.verbose:
+            print("Input shape ", input_ids.size())
+        if self.runtime is not None and self.training and torch.is_grad_enabled():
+            self.runtime.next_micro()
+        # the same embedding, pooler and classifier for the three towers
+        word_embed = self.bert_1.get_input_embeddings()
+        inputs_embeds = word_embed(input_ids)
+        h1 = self._tower(self.bert_1, inputs_embeds, attention_mask, token_type_ids, self.first_device)
+        h2 = self._tower(self.bert_2, inputs_embeds, attention_mask, token_type_ids, self.second_device)
+        h3 = self._tower(self.bert_3, inputs_embeds, attention_mask, token_type_ids, self.second_device)
+        dev = h1.device
+        # mean of the last hidden states; the pooler reads token 0 only, so only those rows are combined
+        first = (h1[:, :1].float() + h2[:, :1].to(dev).float() + h3[:, :1].to(dev).float()) / 3.0
+        out = self.bert_1.head(first.to(h1.dtype), labels.to(dev) if labels is not None else None)
+        return SequenceClassifierOutput(loss=out.loss, logits=out.logits, hidden_states=None, attentions=None)
+
+
+class ConcatBert(nn.Module):
+    """Two-stage layer split inside one process (see the module docstring)."""
+
+    def __init__(self, bert_1, bert_2, device=None, second_device=None):
+        super().__init__()
+        self.bert_1, self.bert_2 = bert_1, bert_2
+        self.device_1 = torch.device(device) if device is not None else None
+        self.second_device = torch.device(second_device) if second_device is not None else self.device_1
+        if self.device_1 is not None:
+            self.bert_1.to(self.device_1)
+        if self.second_device is not None:
+            self.bert_2.to(self.second_device)
+        self.config = bert_2.config
+
+    def forward(self, *args, **kwargs):
+        labels = kwargs.pop("labels", None)
+        input_shape = kwargs["input_ids"].size()
+        hidden_states = self.bert_1.base_model(*args, **kwargs).last_hidden_state
+        dev = self.second_device or hidden_states.device
+        ext = self.bert_2.get_extended_attention_mask(kwargs["attention_mask"], input_shape, dev)
+        hidden_states = hidden_states.to(dev)
+        sequence_output = self.bert_2.base_model.encoder(hidden_states=hidden_states, attention_mask=ext)[0]
+        out = self.bert_2.head(sequence_output, labels.to(dev) if labels is not None else None)
+        return SequenceClassifierOutput(loss=out.loss, logits=out.logits, hidden_states=None, attentions=None)
+
+
+def build_tribert(name_or_cfg="bert-base-cased", first_device=None, second_device=None, seed: Optional[int] = None) -> TriBert:
+    """Three independently initialised classifiers, like three ``from_pretrained`` calls give three modules."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    return TriBert(build_model(name_or_cfg), build_model(name_or_cfg), build_model(name_or_cfg), first_device, second_device)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _TowerRank(nn.Module):
+    """What one rank of a tower-parallel replica owns: rank 0 -> tower 1 (+ shared embedding / pooler /
+    classifier), rank 1 -> towers 2 and 3."""
+
+    def __init__(self, towers: List[nn.Module], indices: List[int]):
+        super().__init__()
+        self.indices = indices
+        for k, t in zip(indices, towers):
+            setattr(self, f"bert_{k}", t)
+        self.config = towers[0].config
+        self.arena = None
+        self.runtime = None
+
+    def towers(self):
+        return [getattr(self, f"bert_{k}") for k in self.indices]
+
+    def arena_segments(self):
+        segs, heads = [], []
+        for k in self.indices:
+            for s in getattr(self, f"bert_{k}").arena_segments(prefix=f"bert_{k}."):
+                (heads if s.name.endswith("head") else segs).append(s)
+        return segs + list(reversed(heads))
+
+    def enable_native(self, arena, seed: int = 0):
+        from ..ops import fused
+
+        rt = fused.NativeRuntime(arena, seed)
+        for k in self.indices:
+            getattr(self, f"bert_{k}").enable_native(arena, prefix=f"bert_{k}.", runtime=rt, site_offset=1024 * k)
+        self.arena, self.runtime = arena, rt
+        return rt
+
+
+def _p2p(ops):
+    from ..parallel.pp import _p2p as run
+
+    run(ops)
+
+
+def tower_step(module, mesh, engine, batch, train: bool = True):
+    """One forward(+backward) of a tower-parallel replica.  Returns (loss, logits) on the first rank."""
+    inner = module.module if hasattr(module, "module") and isinstance(module.module, _TowerRank) else module
+    dp = module if inner is not module else None
+    if dp is not None:
+        dp.auto_arm = False
+    rt = inner.runtime
+    if rt is not None and train:
+        rt.next_micro()
+    dev = engine.device
+    ids, mask, types = batch["input_ids"], batch["attention_mask"], batch["token_type_ids"]
+    B, S = ids.shape
+    H = inner.config.hidden_size
+    arena = inner.arena
+    adt = arena.p16.dtype if (arena is not None and arena.p16 is not None) else torch.float32
+    peer0, peer1 = mesh.peer(0), mesh.peer(1)
+    with torch.set_grad_enabled(train):
+        if mesh.stage == 0:
+            b1 = inner.bert_1
+            emb = b1.get_input_embeddings()(ids)
+            _p2p([dist.P2POp(dist.isend, emb.detach().to(adt).contiguous(), peer1)])
+            # tower 1 reads a detached copy, so the embedding lookup is differentiated ONCE, at the very end,
+            # with the sum of this rank's and the peer's gradient
+            emb_in = emb.detach().requires_grad_() if train else emb
+            h1 = b1.base_model(inputs_embeds=emb_in, attention_mask=mask, token_type_ids=types).last_hidden_state
+            s23 = torch.empty(B, 1, H, dtype=torch.float32, device=dev)
+            _p2p([dist.P2POp(dist.irecv, s23, peer1)])
+            if train:
+                s23.requires_grad_()
+            first = (h1[:, :1].float() + s23) / 3.0
+            out = b1.head(first.to(h1.dtype), batch.get("labels"))
+            if not train:
+                return out.loss, out.logits
+            scale = engine.scaler.scale_tensor() if engine.scaler.enabled else None
+            loss = out.loss * scale.to(out.loss.dtype) if scale is not None else out.loss
+            # tower-1 / head gradients; d(s23) goes to the second rank, which answers with d(embedding)
+            loss.backward()
+            d_emb = torch.empty(B, S, H, dtype=adt, device=dev)
+            _p2p([dist.P2POp(dist.isend, s23.grad.contiguous(), peer1), dist.P2POp(dist.irecv, d_emb, peer1)])
+            if dp is not None:
+                dp.prepare_backward()  # the final backward closes the window: every bucket is reduced after it
+            emb.backward(emb_in.grad.to(emb.dtype) + d_emb.to(emb.dtype))
+            return out.loss.detach(), out.logits
+        emb = torch.empty(B, S, H, dtype=adt, device=dev)
+        _p2p([dist.P2POp(dist.irecv, emb, peer0)])
+        if train:
+            emb.requires_grad_()
+        hs = [t.base_model(inputs_embeds=emb, attention_mask=mask, token_type_ids=types).last_hidden_state
+              for t in inner.towers()]
+        s = hs[0][:, :1].float() + hs[1][:, :1].float()
+        _p2p([dist.P2POp(dist.isend, s.detach().contiguous(), peer0)])
+        if not train:
+            return None, None
+        ds = torch.empty_like(s)
+        _p2p([dist.P2POp(dist.irecv, ds, peer0)])
+        if dp is not None:
+            dp.prepare_backward()
+        s.backward(ds)
+        _p2p([dist.P2POp(dist.isend, emb.grad.contiguous(), peer0)])
+        return None, None
+
+
+def run_tower_training(rank: int, world_size: int, cfg) -> dict:
+    """TriBert training with the towers spread over rank pairs, data parallel across pairs."""
+    from torch.utils.data import DataLoader
+
+    from .. import launch
+    from ..engine import Engine
+    from ..metrics import load_metric
+    from ..models.config import preset
+    from ..optim import AdamW, get_linear_schedule_with_warmup
+    from ..parallel.groups import ParallelMesh
+    from ..recipes import _collator, build_datasets
+    from ..utils.logging import StepLogger
+    from ..utils.seed import set_seed
+
+    launch.init_distributed(cpu=cfg.cpu)
+    mesh = ParallelMesh(world_size, rank, pp=2).build_groups()
+    engine = Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed, process_group=mesh.dp_group,
+                    min_bucket_mb=cfg.min_bucket_mb)
+    model_cfg = preset(cfg.model)
+    train_ds, val_ds = build_datasets(cfg, model_cfg)
+    accum, micro_bs = cfg.accumulation()
+    collate = _collator(cfg, model_cfg)
+    train_dl = DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=micro_bs)
+    eval_dl = DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size)
+    set_seed(cfg.seed)
+    torch.manual_seed(cfg.seed)
+    towers = [build_model(model_cfg) for _ in range(3)]  # same three initialisations on every rank
+    part = _TowerRank([towers[0]], [1]) if mesh.stage == 0 else _TowerRank(towers[1:], [2, 3])
+    optimizer = AdamW(params=part.parameters(), lr=cfg.lr, correct_bias=cfg.correct_bias)
+    part, optimizer, train_dl, eval_dl = engine.prepare(part, optimizer, train_dl, eval_dl)
+    steps_per_epoch = -(-len(train_dl) // accum)
+    sched = get_linear_schedule_with_warmup(optimizer, cfg.num_warmup_steps, steps_per_epoch * cfg.num_epochs)
+    metric = load_metric("glue", "mrpc")
+    log_rank = mesh.stage == 0 and engine.is_main_process
+    logger = StepLogger(log_rank, cfg.log_every, cfg.log_file, samples_per_step=micro_bs * accum * mesh.dp)
+    losses, result, global_step, done = [], {}, 0, False
+    t0 = time.perf_counter()
+    inner_dp = part if hasattr(part, "no_sync") else None
+    for epoch in range(cfg.num_epochs):
+        part.train()
+        train_dl.set_epoch(epoch)
+        pending = 0
+        n_micro = len(train_dl)
+        for step, batch in enumerate(train_dl):
+            pending += 1
+            fire = pending == accum or step == n_micro - 1
+            if inner_dp is not None:
+                inner_dp.require_sync = fire
+            loss, _ = tower_step(part, mesh, engine, batch, train=True)
+            if fire:
+                optimizer.step(overflow_group=mesh.pp_group if engine.scaler.enabled else None)
+                sched.step()
+                optimizer.zero_grad()
+                pending = 0
+                global_step += 1
+                if loss is not None:
+                    if log_rank:
+                        losses.append(float(loss.item()))
+                    logger.log_step(global_step, loss, sched.get_last_lr()[0], engine.scaler)
+                if cfg.max_steps and global_step >= cfg.max_steps:
+                    done = True
+                    break
+        part.eval()
+        seen = 0
+        for batch in eval_dl:
+            _, logits = tower_step(part, mesh, engine, batch, train=False)
+            if logits is not None:
+                preds, refs = engine.gather(logits.argmax(dim=-1)), engine.gather(batch["labels"])
+                valid = max(0, min(preds.shape[0], len(val_ds) - seen))
+                seen += preds.shape[0]
+                metric.add_batch(predictions=preds, references=refs, valid=valid)
+        result = metric.compute() if mesh.stage == 0 else {}
+        logger.log_epoch(epoch, result)
+        dist.barrier()
+        if done:
+            break
+    box = [result if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    out = dict(box[0] or {})
+    out.update({"optimizer_steps": global_step, "wall_s": time.perf_counter() - t0, "losses": losses,
+                "stage": mesh.stage, "replica": mesh.replica})
+    logger.close()
+    return out

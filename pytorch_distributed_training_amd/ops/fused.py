@@ -64,6 +64,7 @@ class LayerNative:
         self.segment = segment
         self.rt = runtime
         self.arena = arena
+        self.site_offset = 0  # distinguishes the dropout streams of equal layer indices in different towers
 
 
 class _LayerFn(torch.autograd.Function):
@@ -79,7 +80,7 @@ class _LayerFn(torch.autograd.Function):
         outs = native().layer_forward(
             x2, m, kvl, nat.w, nat.rt.rng_state, B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            cfg.layer_norm_eps, micro, layer.index)
+            cfg.layer_norm_eps, micro, layer.index + nat.site_offset)
         ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl), x2, outs[1:]
         ctx.meta = (B, S, H, train, micro)
         return outs[0].view(B, S, H)
@@ -95,7 +96,7 @@ class _LayerFn(torch.autograd.Function):
             dy.reshape(B * S, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, nat.rt.rng_state,
             B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            micro, layer.index, acc)
+            micro, layer.index + nat.site_offset, acc)
         ctx.saved = None
         nat.rt.done(nat.segment)
         return dx.view(B, S, H), None, None
@@ -124,6 +125,7 @@ class EmbedNative:
         self.w = [arena.view16(n, s) for n, s in spec]
         self.g = [arena.gview(n, s) for n, s in spec]
         self.segment, self.rt, self.arena = segment, runtime, arena
+        self.site_offset = 0
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -138,7 +140,7 @@ class _EmbedFn(torch.autograd.Function):
         ie = inputs_embeds.reshape(B * S, -1).contiguous() if inputs_embeds is not None else None
         pf, tf = pos_ids.reshape(-1).contiguous(), type_ids.reshape(-1).contiguous()
         y, pre, stats = native().embed_forward(idf, pf, tf, ie, *nat.w, nat.rt.rng_state, cfg.layer_norm_eps,
-                                               cfg.hidden_dropout_prob if train else 0.0, micro, SITE_EMBED)
+                                               cfg.hidden_dropout_prob if train else 0.0, micro, SITE_EMBED + nat.site_offset)
         ctx.emb, ctx.idx, ctx.saved = emb, (idf, pf, tf), (pre, stats)
         ctx.meta = (B, S, train, micro, ie is not None)
         return y.view(B, S, cfg.hidden_size)
@@ -154,7 +156,7 @@ class _EmbedFn(torch.autograd.Function):
         acc = nat.arena.take_accumulate_flag(nat.segment)
         dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.g,
                                        nat.rt.rng_state, cfg.hidden_dropout_prob if train else 0.0, micro,
-                                       SITE_EMBED, cfg.pad_token_id, acc)
+                                       SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc)
         ctx.saved = None
         nat.rt.done(nat.segment)
         return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None)

@@ -67,6 +67,21 @@ def _split_batch(batch: Dict[str, torch.Tensor], m: int) -> List[Dict[str, torch
 
 
 def _p2p(ops) -> None:
+    """Run a group of point-to-point ops that must progress together.  On "nccl" (RCCL) they are fused into
+    one group call on the communicator's stream; gloo has no device transport for send/recv, so GPU tensors
+    are staged through host memory there (CPU plumbing / single-GPU rehearsal only)."""
+    if dist.get_backend() == "gloo" and any(op.tensor.is_cuda for op in ops):
+        staged, works = [], []
+        for op in ops:
+            host = op.tensor.detach().cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            staged.append((op, host))
+            works.append(op.op(host, op.peer))
+        for w in works:
+            w.wait()
+        for op, host in staged:
+            if op.op is dist.irecv:
+                op.tensor.copy_(host)
+        return
     for w in dist.batch_isend_irecv(ops):
         w.wait()
 

@@ -190,3 +190,128 @@ def single_process_reference(batch_size, steps=6):
             if len(losses) >= steps:
                 return losses
     return losses
+
+
+def tower_recipe(rank, world):
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.recipes import run_model_parallel
+
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=32, eval_examples=8, num_epochs=1,
+                      batch_size=8, max_gpu_batch_size=8, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=4,
+                      seed=5, mp_layout="towers")
+    return run_model_parallel(rank, world, cfg)
+
+
+def tribert_single_process(steps=4):
+    """TriBert in one process on the same data / seeds as tower_recipe: the loss curve to match."""
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.models.config import preset
+    from pytorch_distributed_training_amd.models.tribert import TriBert
+    from pytorch_distributed_training_amd.optim import get_linear_schedule_with_warmup
+    from pytorch_distributed_training_amd.recipes import _collator, build_datasets
+    from pytorch_distributed_training_amd.utils.seed import set_seed
+
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=32, eval_examples=8, num_epochs=1,
+                      batch_size=8, seed=5)
+    eng = Engine(cpu=True, seed=5)
+    mc = preset(cfg.model)
+    train_ds, _ = build_datasets(cfg, mc)
+    dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=8)
+    set_seed(5)
+    torch.manual_seed(5)
+    model = TriBert(build_model(mc), build_model(mc), build_model(mc))
+    opt = AdamW(params=model.parameters(), lr=2e-3)
+    model, opt, dl = eng.prepare(model, opt, dl)
+    sched = get_linear_schedule_with_warmup(opt, 1, len(dl))
+    losses = []
+    model.train()
+    dl.set_epoch(0)
+    for batch in dl:
+        loss = model(**batch).loss
+        eng.backward(loss)
+        opt.step(); sched.step(); opt.zero_grad()
+        losses.append(loss.item())
+        if len(losses) >= steps:
+            break
+    return losses
+
+
+# ------------------------------------------------------------------------------------------ GPU rehearsals
+# Two (or four) processes share the ONE GPU of the test box over gloo: RCCL refuses two ranks on one device, but
+# the native kernels, the arena reducer, the pipeline schedule and the tower exchange run exactly as they do
+# with one GPU per rank.
+def gpu_dp_native(rank, world):
+    eng = Engine(fp16=True, seed=7, min_bucket_mb=0.05)
+    assert eng.native and eng.device.type == "cuda"
+    model = _model(seed=rank)
+    opt = AdamW(params=model.parameters(), lr=1e-3)
+    model, opt = eng.prepare(model, opt)
+    inner = eng.unwrap_model(model)
+    batch = {k: v.cuda() for k, v in _global_batch(16).items()}
+    shard = {k: v[rank::world] for k, v in batch.items()}
+    model.train()
+    eng.backward(model(**shard).loss)
+    torch.cuda.synchronize()
+    scale = eng.scaler.get_scale()
+    g_dp = inner.arena.grad.clone() / scale
+    # single-process big batch on the same (broadcast) weights through the same native path
+    ref = _model(seed=0).cuda()
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+
+    arena = ParamArena(ref, eng.device, torch.float16)
+    ref.enable_native(arena, seed=1)
+    ref.train()
+    ref(**batch).loss.backward()
+    err = ((g_dp - arena.grad).norm() / arena.grad.norm()).item()
+    opt.step(); opt.zero_grad()
+    both = [torch.zeros_like(inner.arena.master) for _ in range(world)]
+    dist.all_gather(both, inner.arena.master)
+    return {"err": err, "same": bool(torch.equal(both[0], both[1])), "order": list(model.reducer.launch_order()),
+            "nb": model.reducer.num_buckets()}
+
+
+def gpu_pipeline_recipe(rank, world, layout):
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.recipes import run_model_parallel
+
+    cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
+                      batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
+                      seed=5, mp_layout=layout)
+    if layout == "towers":
+        cfg.batch_size, cfg.max_gpu_batch_size = 8, 8
+    return run_model_parallel(rank, world, cfg)
+
+
+def gpu_single_reference(layout, steps=6):
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.models.config import preset
+    from pytorch_distributed_training_amd.models.tribert import TriBert
+    from pytorch_distributed_training_amd.optim import get_linear_schedule_with_warmup
+    from pytorch_distributed_training_amd.recipes import _collator, build_datasets
+    from pytorch_distributed_training_amd.utils.seed import set_seed
+
+    bs = 8 if layout == "towers" else 16
+    cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
+                      batch_size=bs, seed=5)
+    eng = Engine(fp16=True, seed=5)
+    mc = preset(cfg.model)
+    train_ds, _ = build_datasets(cfg, mc)
+    dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=bs)
+    set_seed(5)
+    torch.manual_seed(5)
+    model = TriBert(build_model(mc), build_model(mc), build_model(mc)) if layout == "towers" else build_model(mc)
+    opt = AdamW(params=model.parameters(), lr=2e-3)
+    model, opt, dl = eng.prepare(model, opt, dl)
+    sched = get_linear_schedule_with_warmup(opt, 1, len(dl) * 2)
+    losses = []
+    model.train()
+    for epoch in range(2):
+        dl.set_epoch(epoch)
+        for batch in dl:
+            loss = model(**batch).loss
+            eng.backward(loss)
+            opt.step(); sched.step(); opt.zero_grad()
+            losses.append(loss.item())
+            if len(losses) >= steps:
+                return losses
+    return losses
