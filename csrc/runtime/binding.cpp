@@ -324,6 +324,9 @@ std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Te
   chk16(pooled, "pooled"); chkf32(W, "W"); chkf32(bias, "bias");
   const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
   TORCH_CHECK(pooled.is_contiguous(), "pooled must be contiguous");
+  if (labels.has_value())
+    TORCH_CHECK(labels->is_contiguous() && labels->scalar_type() == at::kLong && labels->numel() == B,
+                "labels must be a contiguous int64 [B] tensor");
   auto f32 = W.options();
   Tensor logits = at::empty({B, C}, f32);
   Tensor loss = at::zeros({}, f32);

@@ -43,6 +43,7 @@ class TrainConfig:
     fp16: bool = False
     bf16: bool = False
     cpu: bool = False
+    init_scale: float = 65536.0  # initial dynamic loss scale of fp16 runs (torch GradScaler's default)
     # data (no hub access: synthetic MRPC-shaped pairs unless a local TSV directory is given)
     data_dir: Optional[str] = None
     vocab_file: Optional[str] = None

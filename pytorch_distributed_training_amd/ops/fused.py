@@ -237,6 +237,8 @@ class _HeadFn(torch.autograd.Function):
 def classifier_head(pooled: torch.Tensor, nat: HeadNative, labels: Optional[torch.Tensor], p: float,
                     site: int = SITE_HEAD):
     """(logits fp32 [B,C], loss or None) from a 16-bit pooled [B,H]."""
+    if labels is not None:
+        labels = labels.reshape(-1).to(torch.int64).contiguous()  # the kernel indexes labels densely
     logits, loss = _HeadFn.apply(pooled.contiguous(), nat, labels, p, site)
     return logits, (loss if labels is not None else None)
 

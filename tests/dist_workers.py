@@ -241,7 +241,7 @@ def tribert_single_process(steps=4):
 # the native kernels, the arena reducer, the pipeline schedule and the tower exchange run exactly as they do
 # with one GPU per rank.
 def gpu_dp_native(rank, world):
-    eng = Engine(fp16=True, seed=7, min_bucket_mb=0.05)
+    eng = Engine(fp16=True, seed=7, min_bucket_mb=0.05, init_scale=256.0)
     assert eng.native and eng.device.type == "cuda"
     model = _model(seed=rank)
     opt = AdamW(params=model.parameters(), lr=1e-3)
@@ -276,7 +276,7 @@ def gpu_pipeline_recipe(rank, world, layout):
 
     cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
-                      seed=5, mp_layout=layout)
+                      seed=5, mp_layout=layout, init_scale=256.0)
     if layout == "towers":
         cfg.batch_size, cfg.max_gpu_batch_size = 8, 8
     return run_model_parallel(rank, world, cfg)
@@ -293,7 +293,7 @@ def gpu_single_reference(layout, steps=6):
     bs = 8 if layout == "towers" else 16
     cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=bs, seed=5)
-    eng = Engine(fp16=True, seed=5)
+    eng = Engine(fp16=True, seed=5, init_scale=256.0)
     mc = preset(cfg.model)
     train_ds, _ = build_datasets(cfg, mc)
     dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=bs)

@@ -23,8 +23,8 @@ def test_pipeline_native_loss_curve(world):
     ref = W.gpu_single_reference("pipeline")
     res = run_distributed(W.gpu_pipeline_recipe, world, args=("pipeline",))
     got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
-    if world == 4:  # 2 replicas x per-replica batch 16 = global batch 32: compare against itself only for finiteness
-        assert len(got) == 6 and all(x == x for x in got)
+    if world == 4:  # 2 replicas x per-replica batch 16 = global batch 32 => 2 steps per epoch, other batches
+        assert len(got) == 4 and all(x == x and x < 1.5 for x in got)
         return
     assert len(got) == len(ref) == 6
     for a, b in zip(got, ref):
