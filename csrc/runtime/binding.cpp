@@ -472,7 +472,8 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
 
 }  // namespace
 
-void bind_reducer(py::module_& m);  // reducer.cpp
+void bind_reducer(py::module_& m);    // reducer.cpp
+void bind_wordpiece(py::module_& m);  // wordpiece.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "gfx950 kernels + native runtime of pytorch_distributed_training_amd";
@@ -496,4 +497,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("op_attn_fwd", &op_attn_fwd);
   m.def("op_attn_bwd", &op_attn_bwd);
   bind_reducer(m);
+  bind_wordpiece(m);
 }

@@ -18,6 +18,7 @@
 #include <torch/csrc/distributed/c10d/Work.hpp>
 
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 
 namespace py = pybind11;
@@ -46,6 +47,10 @@ class GradBucketReducer {
     }
     world_ = pg_->getSize();
     is_nccl_ = pg_->getBackendName() == "nccl";
+    // PDT_FORCE_COLLECTIVES=1 issues the collectives even in a 1-rank group (exercises the RCCL call path on
+    // a single-GPU test box)
+    const char* force = std::getenv("PDT_FORCE_COLLECTIVES");
+    force_ = force && force[0] == '1';
     reset();
   }
 
@@ -92,7 +97,7 @@ class GradBucketReducer {
   // rank `root`'s values of `t` (any flat tensor, e.g. the parameter arena) to everyone, in chunks
   void broadcast(Tensor t, int64_t root, int64_t chunk_elems) {
     TORCH_CHECK(t.dim() == 1 && t.is_contiguous(), "broadcast expects a flat contiguous tensor");
-    if (world_ == 1) return;
+    if (world_ == 1 && !force_) return;
     std::vector<c10::intrusive_ptr<c10d::Work>> ws;
     for (int64_t o = 0; o < t.numel(); o += chunk_elems) {
       std::vector<Tensor> v{t.narrow(0, o, std::min(chunk_elems, t.numel() - o))};
@@ -130,7 +135,7 @@ class GradBucketReducer {
   }
   void launch(int b) {
     order_.push_back(b);
-    if (world_ == 1) return;  // nothing to exchange; gradients are already the global ones
+    if (world_ == 1 && !force_) return;  // nothing to exchange; gradients are already the global ones
     Tensor buf = views_[b];
     if (comm_dtype_.has_value() && *comm_dtype_ != buf.scalar_type()) {
       staged_[b] = buf.to(*comm_dtype_);  // halve the bytes on the wire; accumulation stays fp32 in the arena
@@ -150,7 +155,7 @@ class GradBucketReducer {
   bool average_;
   c10::optional<at::ScalarType> comm_dtype_;
   int nb_ = 0, world_ = 1, next_ = 0;
-  bool is_nccl_ = false, sync_ = true, active_ = false;
+  bool is_nccl_ = false, sync_ = true, active_ = false, force_ = false;
   std::vector<Tensor> views_, staged_;
   std::vector<int64_t> ready_, order_;
   std::vector<c10::intrusive_ptr<c10d::Work>> works_;
