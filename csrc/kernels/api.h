@@ -41,6 +41,9 @@ typedef struct PdtGemm {
   PdtRng rng;
   int k_per_split;
   int tiles_m, tiles_n, splits;
+  // optional fp32 [N]: column sums of the stored C (the bias gradient of the layer that produced C's input)
+  // are added here with fp32 atomics, one add per column per 32-row slab of a wave
+  float* colsum;
 } PdtGemm;
 
 // tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves, one barrier per K-tile), 2 = 256x256 ping-pong

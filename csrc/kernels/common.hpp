@@ -118,11 +118,32 @@ __device__ __forceinline__ uint32_t drop_keep8(const DropKey& k, uint64_t g, uin
   return bits;
 }
 
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+// Exact-erf GELU evaluated with the Abramowitz-Stegun 7.1.26 rational form of erf (|error| < 1.5e-7, far
+// below 16-bit output rounding): one v_exp_f32 + one v_rcp_f32 + a 5-term Horner chain.  With x = u/sqrt(2) the
+// exponential exp(-x^2) = exp(-u^2/2) is also the Gaussian of the derivative, so gelu and gelu' share it.
+// The GEMM epilogues call this once per output element; the libm erff costs ~3x more VALU work there.
+struct GeluParts {
+  float cdf;  // Phi(u) = 0.5 * (1 + erf(u / sqrt(2)))
+  float pdf;  // phi(u) = exp(-u^2 / 2) / sqrt(2 pi)
+};
+__device__ __forceinline__ GeluParts gelu_parts(float u) {
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float e = __expf(-x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * e;  // 0.5 * erfc(|x|)
+  GeluParts r;
+  r.cdf = u >= 0.f ? 1.0f - half_erfc : half_erfc;
+  r.pdf = 0.3989422804014327f * e;
+  return r;
+}
+__device__ __forceinline__ float gelu_f(float u) { return u * gelu_parts(u).cdf; }
 __device__ __forceinline__ float gelu_grad_f(float u) {
-  float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-  float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
-  return cdf + u * pdf;
+  const GeluParts g = gelu_parts(u);
+  return fmaf(u, g.pdf, g.cdf);
 }
 
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (and its

@@ -160,7 +160,23 @@ struct GemmKernel {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += r[i];
     }
-    *reinterpret_cast<short8*>((T*)g.C + (size_t)m * g.ldc + n) = pack8<T>(v);
+    const short8 packed = pack8<T>(v);
+    *reinterpret_cast<short8*>((T*)g.C + (size_t)m * g.ldc + n) = packed;
+    if (g.colsum) unpack8<T>(packed, v);  // column sums are taken over exactly what was stored
+  }
+
+  // add the 8 per-column partial sums a lane collected (over the rows it handled) to g.colsum: first combine
+  // the 8 lanes that share a column block (lane>>3 = row inside a pass), then one lane issues the atomics
+  static __device__ __forceinline__ void flush_colsum(const GemmArgs& g, int n, bool n_ok, float (&cs)[8], int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = cs[i];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if ((lane >> 3) == 0 && n_ok) atomicAdd(g.colsum + n + i, v);
+      cs[i] = 0.f;
+    }
   }
 
   static __device__ __forceinline__ void run(const GemmArgs& g) {
@@ -255,6 +271,8 @@ struct GemmKernel {
           *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
         }
       }
+      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int n = n0 + wn * WTN + (lane & 7) * 8;
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {  // not unrolled: the epilogue math is emitted once per row pair
         const int row = it * 8 + (lane >> 3), jc = lane & 7;
@@ -263,9 +281,15 @@ struct GemmKernel {
         const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const int m = m0 + wm * WTM + ip * 32 + row;
-        const int n = n0 + wn * WTN + jc * 8;
-        if (m < g.M && n < g.N) epilogue8(g, m, n, v, dk);
+        if (m < g.M && n < g.N) {
+          epilogue8(g, m, n, v, dk);
+          if (g.colsum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs[i] += v[i];
+          }
+        }
       }
+      if (g.colsum) flush_colsum(g, n, n < g.N, cs, lane);
     }
   }
 };

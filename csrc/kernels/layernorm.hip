@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Backward.  Each wave walks rows (grid-stride) and keeps the column partial sums of its lanes'
 // columns in registers; the 4 waves of a block are combined through LDS and written as one
 // partial row, reduced afterwards by colsum_finish_kernel (deterministic, no atomics).
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ stats, const T* __restrict__ gamma,
                                                      T* __restrict__ dx, T* __restrict__ ddrop,
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = H >> 3;
-  float pg[LN_MAX_CHUNKS][8], pb[LN_MAX_CHUNKS][8], pd[LN_MAX_CHUNKS][8], gam[LN_MAX_CHUNKS][8];
+  float pg[NCH][8], pb[NCH][8], pd[NCH][8], gam[NCH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; pd[i][j] = 0.f; gam[i][j] = 0.f; }
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const float invH = 1.0f / H;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float g[LN_MAX_CHUNKS][8], xh[LN_MAX_CHUNKS][8];
+    float g[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         float d[8], xv[8];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
         float o[8];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   // combine the block's 4 waves: LDS [4][3][H] fp32
   float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
 #pragma unroll
@@ -233,20 +233,25 @@ extern "C" int pdt_layernorm_bwd(int dtype, const void* dy, const void* x, const
   nb = nb < 1 ? 1 : (nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   *nblk = nb;
   const size_t lds = (size_t)4 * 3 * H * sizeof(float);
-  if (lds > 65536) {  // H > 1365 needs the opt-in LDS size
-    hipError_t e = dtype == PDT_F16
-                       ? hipFuncSetAttribute((const void*)ln_bwd_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                       : hipFuncSetAttribute((const void*)ln_bwd_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+  // registers are sized for the row length: 1 / 2 / 4 chunks of 8 elements per lane (H <= 512 / 1024 / 2048)
+#define PDT_LNB(TT, NCH)                                                                                          \
+  do {                                                                                                            \
+    if (lds > 65536) {                                                                                            \
+      hipError_t e = hipFuncSetAttribute((const void*)ln_bwd_kernel<TT, NCH>,                                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      if (e != hipSuccess) return (int)e;                                                                         \
+    }                                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<TT, NCH>), dim3(nb), dim3(256), lds, (hipStream_t)stream, (const TT*)dy,     \
+                       (const TT*)x, stats, (const TT*)gamma, (TT*)dx, (TT*)ddrop, partial, rows, H, drop_scale,  \
+                       drop_thr, rng);                                                                            \
+  } while (0)
+  const int nch = H <= 512 ? 1 : (H <= 1024 ? 2 : 4);
+  if (dtype == PDT_F16) {
+    if (nch == 1) PDT_LNB(_Float16, 1); else if (nch == 2) PDT_LNB(_Float16, 2); else PDT_LNB(_Float16, 4);
+  } else {
+    if (nch == 1) PDT_LNB(__bf16, 1); else if (nch == 2) PDT_LNB(__bf16, 2); else PDT_LNB(__bf16, 4);
   }
-  if (dtype == PDT_F16)
-    hipLaunchKernelGGL(ln_bwd_kernel<_Float16>, dim3(nb), dim3(256), lds, (hipStream_t)stream, (const _Float16*)dy,
-                       (const _Float16*)x, stats, (const _Float16*)gamma, (_Float16*)dx, (_Float16*)ddrop, partial, rows,
-                       H, drop_scale, drop_thr, rng);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, dim3(nb), dim3(256), lds, (hipStream_t)stream, (const __bf16*)dy,
-                       (const __bf16*)x, stats, (const __bf16*)gamma, (__bf16*)dx, (__bf16*)ddrop, partial, rows, H,
-                       drop_scale, drop_thr, rng);
+#undef PDT_LNB
   return (int)hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ struct Epi {
   Tensor* aux = nullptr;
   double drop_p = 0.0;
   PdtRng rng{nullptr, 0, 0};
+  float* colsum = nullptr;  // fp32 [N]: += column sums of the stored output (a bias gradient)
 };
 
 void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, int N, int K, const Epi& e, int tile = -1) {
@@ -70,6 +71,7 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
   g.drop_thr = thr16(e.drop_p);
   g.drop_scale = keep_scale(e.drop_p);
   g.rng = e.rng;
+  g.colsum = e.colsum;
   check(pdt_gemm(dt_code(A), layout, tile, &g, cur_stream()), "gemm");
 }
 
@@ -210,11 +212,11 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
   LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2),
                        accumulate);
-  // FFN2 dgrad fused with GELU' ; wgrad
-  Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
+  // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU, fp32 atomics) ; wgrad
+  if (!accumulate) gr[7].zero_();
+  Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u); e_dg.colsum = gr[7].data_ptr<float>();
   Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
   gemm_tn_into(l2.ddrop, gact, gr[8], accumulate);
-  colsum_into(du, gr[7], accumulate);
   // FFN1 dgrad + residual gradient ; wgrad
   Epi e_add; e_add.kind = PDT_EPI_ADD_RES; e_add.res = &l2.dx;
   Tensor dx1 = gemm_nn(du, w[6], e_add);
@@ -407,9 +409,11 @@ void cast_to_16(const Tensor& src, Tensor dst) {
 // ---------------------------------------------------------------------------------------------------
 Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int64_t epi,
                const c10::optional<Tensor>& bias, const c10::optional<Tensor>& res, c10::optional<Tensor> aux,
-               const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site, int64_t tile) {
+               const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site, int64_t tile,
+               c10::optional<Tensor> colsum) {
   DeviceGuard guard(A.device());
   Epi e; e.kind = (int)epi; e.drop_p = drop_p;
+  if (colsum.has_value()) { chkf32(*colsum, "colsum"); e.colsum = colsum->data_ptr<float>(); }
   if (bias.has_value()) e.bias = &*bias;
   if (res.has_value()) e.res = &*res;
   if (aux.has_value()) e.aux = &*aux;
@@ -490,7 +494,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("grad_check", &grad_check);
   m.def("scaler_update", &scaler_update);
   m.def("cast_to_16", &cast_to_16);
-  m.def("op_gemm", &op_gemm);
+  m.def("op_gemm", &op_gemm, py::arg("layout"), py::arg("A"), py::arg("B"), py::arg("epi"), py::arg("bias"),
+        py::arg("res"), py::arg("aux"), py::arg("rng_state"), py::arg("drop_p"), py::arg("micro"), py::arg("site"),
+        py::arg("tile"), py::arg("colsum") = py::none());
   m.def("op_gemm_tn", &op_gemm_tn);
   m.def("op_layernorm_fwd", &op_layernorm_fwd);
   m.def("op_layernorm_bwd", &op_layernorm_bwd);

@@ -117,6 +117,11 @@ def test_gemm_nn_dgrad(dtype, tile, M, N, K):
     uf = u.float().requires_grad_()
     F.gelu(uf).backward(ref)
     assert rel_err(out, uf.grad) < 1e-2
+    # fused bias gradient: column sums of the stored output, accumulated into an fp32 vector
+    cs = torch.ones(N, device="cuda")
+    out2 = C().op_gemm("nn", dY, W, 4, None, None, u, None, 0.0, 0, 0, tile, cs)
+    assert torch.equal(out2, out)
+    torch.testing.assert_close(cs, 1 + out.float().sum(0), rtol=2e-3, atol=2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -369,3 +374,25 @@ def test_gemm_pingpong_large_k_repeatable(layout):
         assert rel_err(first, ref) < 3e-3, (layout, M, N, K)
         for _ in range(20):
             assert torch.equal(run(), first), (layout, M, N, K)
+
+
+def test_gelu_epilogue_matches_erf_gelu_closely():
+    """The epilogue evaluates exact-erf GELU with a rational erf (|err| < 1.5e-7): indistinguishable after
+    rounding to 16 bits, also in the tails."""
+    M, N, K = 256, 256, 64
+    A = torch.zeros(M, K, device="cuda", dtype=torch.float16)
+    W = torch.zeros(N, K, device="cuda", dtype=torch.float16)
+    vals = torch.linspace(-9, 9, N, device="cuda")
+    b = vals.to(torch.float16)
+    u = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    g = C().op_gemm("nt", A, W, 2, b, None, u, None, 0.0, 0, 0, 0)
+    ref = F.gelu(b.float()).to(torch.float16)
+    assert (g[0].float() - ref.float()).abs().max().item() <= 1e-3
+    assert torch.equal(g[0], g[-1])
+    ones = torch.ones(M, K, device="cuda", dtype=torch.float16)
+    eye = torch.zeros(K, N, device="cuda", dtype=torch.float16)
+    eye[0] = 1.0  # dY @ eye = 1 everywhere -> output = gelu'(u)
+    d = C().op_gemm("nn", ones, eye, 4, None, None, u, None, 0.0, 0, 0, 0)
+    bf = b.float().requires_grad_()
+    F.gelu(bf).sum().backward()
+    assert (d[0].float() - bf.grad).abs().max().item() <= 2e-3
