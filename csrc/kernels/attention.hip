@@ -12,7 +12,10 @@
 
 namespace pdt {
 
-constexpr int HD = 64;  // head dim
+constexpr int HD = 64;       // head dim
+constexpr int ATT_WAVES = 8;  // waves per workgroup: 8 x 16 = 128 query rows (or keys) share one K/V (or Q/dO) image
+constexpr int ATT_THREADS = ATT_WAVES * 64;
+constexpr int ATT_ROWS = ATT_WAVES * 16;
 
 struct AttnArgs {
   const void* qkv;   // [B*S, 3H]
@@ -46,7 +49,7 @@ __device__ __forceinline__ bool attn_keep(const DropKey& dk, uint32_t bh, uint32
 // cooperative load of `nrows_pad` rows of 64 16-bit values (row stride `stride` elements) into an image
 template <typename T>
 __device__ __forceinline__ void load_image(char* img, const T* src, int stride, int nvalid, int nrows_pad, int tid) {
-  for (int idx = tid; idx < nrows_pad * 8; idx += 256) {
+  for (int idx = tid; idx < nrows_pad * 8; idx += ATT_THREADS) {
     const int row = idx >> 3, c = idx & 7;
     short8 v = short8{0, 0, 0, 0, 0, 0, 0, 0};
     if (row < nvalid) v = *reinterpret_cast<const short8*>(src + (size_t)row * stride + c * 8);
@@ -97,7 +100,7 @@ __device__ __forceinline__ float quad_max(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int SMAX>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   constexpr int NPB = SMAX / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int npb = (kvl + 31) >> 5;
   load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
   load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
-  for (int k = tid; k < npb * 32; k += 256) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
+  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
   __syncthreads();
 
-  const int q0 = blockIdx.y * 64 + wave * 16;
+  const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
   if (q0 >= S) return;
   const int lm = lane & 15, g = lane >> 4;
   const int q = q0 + lm, qc = min(q, S - 1);
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <typename T, int SMAX>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int NPB = SMAX / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -198,10 +201,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const int npb = (kvl + 31) >> 5;
   load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
   load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
-  for (int k = tid; k < npb * 32; k += 256) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
+  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
   __syncthreads();
 
-  const int q0 = blockIdx.y * 64 + wave * 16;
+  const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
   if (q0 >= S) return;
   const int lm = lane & 15, g = lane >> 4;
   const int q = q0 + lm, qc = min(q, S - 1);
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, int SMAX>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
   char* dimg = smem + SMAX * 128;
@@ -275,13 +278,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
   const int nqb = (S + 31) >> 5;  // 32-row query blocks
   const int kvl = min(a.kv_len[b], S);
-  const int k0 = blockIdx.y * 64 + wave * 16;
+  const int k0 = blockIdx.y * ATT_ROWS + wave * 16;
   // keys at or beyond kv_len receive exactly zero gradient: the block only has to write zeros
-  const bool active = blockIdx.y * 64 < kvl;
+  const bool active = blockIdx.y * ATT_ROWS < kvl;
   if (active) {
     load_image<T>(qimg, base, ld, S, nqb * 32, tid);
     load_image<T>(dimg, dob, a.H, S, nqb * 32, tid);
-    for (int i = tid; i < nqb * 32; i += 256) {
+    for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
       lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
       del_s[i] = i < S ? a.delta[(size_t)bh * S + i] : 0.f;
     }
@@ -354,7 +357,7 @@ static int launch_attn(KernT kern, const AttnArgs& a, int smax, hipStream_t stre
   const size_t lds = (size_t)2 * smax * 128 + (size_t)2 * smax * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + 63) / 64), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a);
   return (int)hipGetLastError();
 }
 

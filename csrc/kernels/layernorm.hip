@@ -148,23 +148,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 struct ColsumOuts { float* out[4]; };
 
-// Each block owns 32 columns: 8 row groups x 32 columns; a thread sums every 8th partial row of its column
-// (coalesced 128-B reads across the 32 lanes), then the 8 groups are combined in a fixed order through LDS.
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nblk, int H,
-                                                            int nseg, ColsumOuts outs, int accumulate) {
-  __shared__ float red[8][33];
+// Each block owns 32 columns: 32 row groups x 32 columns; a thread sums every 32nd partial row of its column
+// (coalesced 128-B reads across the 32 lanes, 4 independent accumulators to keep loads in flight), then the
+// row groups are combined in a fixed order through LDS.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblk, int H,
+                                                             int nseg, ColsumOuts outs, int accumulate) {
+  __shared__ float red[32][33];
   const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int total = nseg * H;
   const int idx = blockIdx.x * 32 + cg;
-  float s = 0.f;
-  if (idx < total)
-    for (int b = rg; b < nblk; b += 8) s += partial[(size_t)b * total + idx];
-  red[rg][cg] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < total) {
+    int b = rg;
+    for (; b + 96 < nblk; b += 128) {
+      s0 += partial[(size_t)b * total + idx];
+      s1 += partial[(size_t)(b + 32) * total + idx];
+      s2 += partial[(size_t)(b + 64) * total + idx];
+      s3 += partial[(size_t)(b + 96) * total + idx];
+    }
+    for (; b < nblk; b += 32) s0 += partial[(size_t)b * total + idx];
+  }
+  red[rg][cg] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0 && idx < total) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][cg];
+    for (int r = 0; r < 32; ++r) t += red[r][cg];
     const int seg = idx / H, c = idx % H;
     float* o = seg == 0 ? outs.out[0] : (seg == 1 ? outs.out[1] : (seg == 2 ? outs.out[2] : outs.out[3]));
     if (o) o[c] = accumulate ? o[c] + t : t;
@@ -260,7 +269,7 @@ extern "C" int pdt_colsum_finish(const float* partial, int nblk, int H, int nseg
   if (nseg < 1 || nseg > 4) return -3;
   ColsumOuts outs{{o0, o1, o2, o3}};
   const int total = nseg * H;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nblk,
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
                      H, nseg, outs, accumulate);
   return (int)hipGetLastError();
 }
