@@ -1,22 +1,41 @@
 // 256x256x64 "ping-pong" MFMA GEMM for gfx950: the large-shape kernel of this library.
 //
 // 8 waves = 2 groups of 4 (one wave of each group per SIMD).  Each K-tile is cut into four 16-KiB half
-// tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255) and four phases; a wave owns output rows
-// {mh*128 + wr*64 .. +63 | mh=0,1} x cols {nh*128 + wc*32 .. +31 | nh=0,1}, so phase (mh,nh) needs exactly
-// half tile A[mh] and B[nh].  Per phase a wave does: LDS fragment reads for the quadrant, ONE half-tile
-// LDS-DMA prefetch (2 x buffer_load ... lds), barrier, 16 MFMAs, barrier.  The second wave group runs one
-// barrier behind the first, so on every SIMD one wave is in its MFMA section while its partner is in its
-// load section: the matrix pipe stays busy and the LDS/VMEM traffic hides under it.
+// tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255); a wave owns output rows
+// {mh*128 + wr*64 .. +63 | mh=0,1} x cols {nh*128 + wc*32 .. +31 | nh=0,1}, so output quadrant (mh,nh) needs
+// exactly half tile A[mh] and B[nh].  A K-tile is two phases: X reads A0,B0,B1 and computes quadrants
+// (0,0),(0,1); Y reads A1 and computes (1,1),(1,0).  Per phase a wave does: LDS fragment reads, TWO half-tile
+// LDS-DMA prefetches (4 x buffer_load ... lds), lgkmcnt(0), barrier, 32 MFMAs, barrier.  The second wave
+// group runs one barrier behind the first, so on every SIMD one wave is in its MFMA section while its
+// partner is in its load section: the matrix pipe stays busy and the LDS/VMEM traffic hides under it.
+// (A four-phase variant, one quadrant per phase, is kept behind PDT_PHASES=4; it measured ~3 % slower:
+// twice as many barriers.)
 //
-// Prefetch distance is 6 half tiles (1.5 K-tiles) over a 2-deep LDS ring (128 KiB): half tile (t+2, i)
-// re-uses the slot of (t, i) and is issued in phase 4t+2+i, at least two barriers after the last wave has
-// finished reading (t, i).  LDS-DMA completion is tracked with ONE counted wait per K-tile
-// (s_waitcnt vmcnt(4): everything but the two newest half tiles has landed) placed before a barrier;
+// Prefetch distance is 6 half tiles (1.5 K-tiles) over a 2-deep LDS ring (128 KiB).  A wave retires its
+// LDS reads before the barrier that closes its load section, so a slot may be re-staged in the very next
+// phase: X(t) issues (t+1: B1, A1) into slots last read in X(t-1)/Y(t-1), Y(t) issues (t+2: A0, B0) into
+// slots last read in X(t).  LDS-DMA completion is tracked with ONE counted wait per K-tile
+// (s_waitcnt vmcnt(4) in Y: everything but the two newest half tiles has landed) placed before a barrier;
 // the data is first read in the NEXT phase, i.e. after a barrier every issuing wave has passed behind its
 // wait.  Out-of-range half tiles (beyond K or the matrix edge) are still issued with an out-of-bounds
 // offset - the buffer unit writes zeros - so the wait count is the same in every iteration.
 #pragma once
 #include "gemm.hpp"
+
+// PDT_ABLATE (bench/micro/gemm8_ablate.hip only): compile parts of a phase out to see what bounds the loop
+#ifndef PDT_ABLATE
+#define PDT_ABLATE 0
+#endif
+// PDT_PRIO (experiments): 0 = raise priority around the MFMA cluster, 1 = no priority changes,
+// 2 = raise priority in the load section instead
+#ifndef PDT_PRIO
+#define PDT_PRIO 0
+#endif
+// PDT_PHASES: phases per K-tile.  4 = one output quadrant (16 MFMAs) per phase; 2 = two quadrants (32 MFMAs)
+// per phase, half as many barriers.
+#ifndef PDT_PHASES
+#define PDT_PHASES 2
+#endif
 
 namespace pdt {
 
@@ -34,9 +53,11 @@ struct Gemm8 {
   static constexpr int OFF_A0 = 0, OFF_B0 = HALF_BYTES, OFF_B1 = 2 * HALF_BYTES, OFF_A1 = 3 * HALF_BYTES;
 
   static __device__ __forceinline__ short8 fragA(const char* img, int x0, int ks, int lane) {
+    if (PDT_ABLATE == 2) { short8 r; for (int i = 0; i < 8; ++i) r[i] = (short)(x0 + ks + lane); return r; }
     return AKS ? Base::template frag_ks<128>(img, x0, ks, lane) : Base::frag_kc(img, x0, ks, lane);
   }
   static __device__ __forceinline__ short8 fragB(const char* img, int x0, int ks, int lane) {
+    if (PDT_ABLATE == 2) { short8 r; for (int i = 0; i < 8; ++i) r[i] = (short)(x0 * 3 + ks + lane); return r; }
     return BKS ? Base::template frag_ks<128>(img, x0, ks, lane) : Base::frag_kc(img, x0, ks, lane);
   }
 
@@ -72,6 +93,7 @@ struct Gemm8 {
     // Tiles at or beyond nkt read out of bounds (kt*kstep runs past `records`, or the K check fails): zeros.
 #define PDT_STAGE(I, TILE)                                                                   \
   do {                                                                                       \
+    if (PDT_ABLATE == 1 && (TILE) > 1) break;                                                \
     char* b_ = smem + ((TILE)&1) * BUF_BYTES;                                                \
     if ((I) == 0) la0.issue(b_ + OFF_A0, (TILE), klen, wave);                                \
     else if ((I) == 1) lb0.issue(b_ + OFF_B0, (TILE), klen, wave);                           \
@@ -92,12 +114,15 @@ struct Gemm8 {
 
 #define PDT_MFMA_QUADRANT(MH, FB, NH)                                                        \
   do {                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                           \
+    if (PDT_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                        \
+    if (PDT_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                        \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                         \
-      acc[(MH)*4 + mi][(NH)*2 + ni] = Half16<T>::mfma(FB[ni][ks], fa[mi][ks], acc[(MH)*4 + mi][(NH)*2 + ni]); \
-    __builtin_amdgcn_s_setprio(0);                                                           \
+      if (PDT_ABLATE == 3) { asm volatile("" :: "v"(FB[ni][ks]), "v"(fa[mi][ks])); }         \
+      else acc[(MH)*4 + mi][(NH)*2 + ni] = Half16<T>::mfma(FB[ni][ks], fa[mi][ks], acc[(MH)*4 + mi][(NH)*2 + ni]); \
+    if (PDT_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                        \
+    if (PDT_PRIO == 2) __builtin_amdgcn_s_setprio(1);                                        \
   } while (0)
 
 #define PDT_SYNC_LOADS()                                                                     \
@@ -114,6 +139,7 @@ struct Gemm8 {
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
 
+#if PDT_PHASES == 4
     for (int t = 0; t < nkt; ++t) {
       const char* buf = smem + (t & 1) * BUF_BYTES;
       // ---- phase 0: quadrant (A0, B0) -----------------------------------------------------------
@@ -155,6 +181,53 @@ struct Gemm8 {
       PDT_MFMA_QUADRANT(1, fb0, 0);
       PDT_END_PHASE();
     }
+#else
+    // Two phases per K-tile.  The LDS reads of a phase are retired (lgkmcnt(0)) BEFORE the barrier that ends
+    // its load section - the wave would wait at that barrier for its partner's MFMA section anyway - so a
+    // slot may be re-staged one phase after its last read:
+    //   X(t): read A0,B0,B1 of tile t ; issue (t+1: B1, A1) ; MFMA (A0,B0),(A0,B1)
+    //   Y(t): read A1 of tile t       ; issue (t+2: A0, B0) ; wait vmcnt(4) => tile t+1 landed ; MFMA (A1,B1),(A1,B0)
+#define PDT_SYNC_LOADS2()                                                                    \
+  do {                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    __builtin_amdgcn_s_barrier();                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+    for (int t = 0; t < nkt; ++t) {
+      const char* buf = smem + (t & 1) * BUF_BYTES;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb0[ni][ks] = fragB(buf + OFF_B0, bcol + ni * 16, ks, lane);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = fragA(buf + OFF_A0, arow + mi * 16, ks, lane);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fb1[ni][ks] = fragB(buf + OFF_B1, bcol + ni * 16, ks, lane);
+      PDT_STAGE(2, t + 1);
+      PDT_STAGE(3, t + 1);
+      PDT_SYNC_LOADS2();
+      PDT_MFMA_QUADRANT(0, fb0, 0);
+      PDT_MFMA_QUADRANT(0, fb1, 1);
+      PDT_END_PHASE();
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = fragA(buf + OFF_A1, arow + mi * 16, ks, lane);
+      PDT_STAGE(0, t + 2);
+      PDT_STAGE(1, t + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      PDT_SYNC_LOADS2();
+      PDT_MFMA_QUADRANT(1, fb1, 1);
+      PDT_MFMA_QUADRANT(1, fb0, 0);
+      PDT_END_PHASE();
+    }
+#undef PDT_SYNC_LOADS2
+#endif
     // re-align the two wave groups, drain the (zero-filling) DMA still in flight, then reuse LDS
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
