@@ -127,14 +127,15 @@ struct GemmKernel {
     return r;
   }
 
-  // ---- epilogue on 8 consecutive columns of one row ---------------------------------------------
-  static __device__ __forceinline__ void epilogue8(const GemmArgs& g, int m, int n, float (&v)[8], const DropKey& dk) {
-    const int epi = g.epi;
+  // ---- epilogue ------------------------------------------------------------------------------------
+  // Math on 8 consecutive columns of one row.  `bias` holds the 8 bias values of these columns (zeros when the
+  // epilogue has none), `ext` the 8 side-input values of this row: aux for MUL_DGELU, res for *_RES.
+  template <int epi>
+  static __device__ __forceinline__ void epilogue8(const GemmArgs& g, int m, int n, float (&v)[8], const float (&bias)[8],
+                                                   const short8& ext, const DropKey& dk) {
     if (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_TANH) {
-      float b[8];
-      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.bias + n), b);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += b[i];
+      for (int i = 0; i < 8; ++i) v[i] += bias[i];
     }
     if (epi == EPI_BIAS_GELU) {
       *reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n) = pack8<T>(v);
@@ -145,7 +146,7 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
     } else if (epi == EPI_MUL_DGELU) {
       float u[8];
-      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.aux + (size_t)m * g.ldaux + n), u);
+      unpack8<T>(ext, u);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
     }
@@ -156,7 +157,7 @@ struct GemmKernel {
     }
     if (epi == EPI_BIAS_DROP_RES || epi == EPI_ADD_RES) {
       float r[8];
-      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.res + (size_t)m * g.ldr + n), r);
+      unpack8<T>(ext, r);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += r[i];
     }
@@ -177,6 +178,101 @@ struct GemmKernel {
       if ((lane >> 3) == 0 && n_ok) atomicAdd(g.colsum + n + i, v);
       cs[i] = 0.f;
     }
+  }
+
+  // The accumulators of a wave (2*NIP row blocks of 16 x 64 columns) leave through a wave-private 32-row x
+  // 64-col fp32 LDS staging area (16-B chunks XOR-swizzled by row&15), one pair of row blocks ("ip") at a time,
+  // so that every global access is 16 B per lane on full 128-B row segments.  Lane -> (row it*8 + lane>>3,
+  // column block lane&7); `n` is the first of the lane's 8 global columns (the same for every row) and
+  // mbase(ip) the global row of staged row 0.  The side inputs (aux / res) of row-block pair ip+1 are fetched
+  // before pair ip is processed, so their latency hides under the math and the LDS transpose; the bias is
+  // read once; the column sums are kept in registers over the whole wave tile and flushed once.
+  template <int NIP, int epi, typename MBase>
+  static __device__ __forceinline__ void staged_epilogue_as(const GemmArgs& g, float4v (&acc)[2 * NIP][4], char* stg, int n,
+                                                            MBase mbase, int lane) {
+    const int lm = lane & 15, lg = lane >> 4, jc = lane & 7, rsub = lane >> 3;
+    const bool n_ok = n < g.N;
+    const DropKey dk = drop_key(g.rng);
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_TANH) && n_ok)
+      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.bias + n), bias);
+    const bool dgelu = epi == EPI_MUL_DGELU;
+    const bool has_ext = dgelu || epi == EPI_BIAS_DROP_RES || epi == EPI_ADD_RES;
+    const T* ext = dgelu ? (const T*)g.aux : (const T*)g.res;
+    const int ldx = dgelu ? g.ldaux : g.ldr;
+    short8 xin[2][4];
+    auto fetch = [&](int ip, short8(&dst)[4]) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = mbase(ip) + it * 8 + rsub;
+        dst[it] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (has_ext && n_ok && m < g.M) dst[it] = *reinterpret_cast<const short8*>(ext + (size_t)m * ldx + n);
+      }
+    };
+    fetch(0, xin[0]);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ip = 0; ip < NIP; ++ip) {
+      if (ip + 1 < NIP) fetch(ip + 1, xin[(ip + 1) & 1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 16 + lm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int chunk = (j * 4 + lg) ^ lm;
+          *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        const int key = row & 15;
+        const float4v lo = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
+        const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int m = mbase(ip) + row;
+        if (m < g.M && n_ok) {
+          epilogue8<epi>(g, m, n, v, bias, xin[ip & 1][it], dk);
+          if (g.colsum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs[i] += v[i];
+          }
+        }
+      }
+    }
+    if (g.colsum) flush_colsum(g, n, n_ok, cs, lane);
+  }
+
+  // The epilogue kind is a run-time argument of the kernel but a compile-time parameter of the (fully unrolled)
+  // epilogue code: one specialised copy per kind the operand layout is used with, selected by one uniform
+  // branch, so a tile only ever fetches the instructions of its own epilogue.
+  //   NT (forward):        PLAIN, BIAS, BIAS_GELU, BIAS_DROP_RES, BIAS_TANH
+  //   NN (data gradient):  PLAIN, MUL_DGELU, ADD_RES
+  //   TN (weight gradient) only ever writes split-K slabs (handled by the caller); PLAIN is kept for tests.
+  static constexpr bool epilogue_supported(int epi) {
+    return epi == EPI_PLAIN || epi == EPI_SLAB_F32 ||
+           (!AKS && !BKS && (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_TANH)) ||
+           (!AKS && BKS && (epi == EPI_MUL_DGELU || epi == EPI_ADD_RES));
+  }
+  template <int NIP, typename MBase>
+  static __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, float4v (&acc)[2 * NIP][4], char* stg, int n,
+                                                         MBase mbase, int lane) {
+    if (!AKS && !BKS) {
+      switch (g.epi) {
+        case EPI_BIAS: return staged_epilogue_as<NIP, EPI_BIAS>(g, acc, stg, n, mbase, lane);
+        case EPI_BIAS_GELU: return staged_epilogue_as<NIP, EPI_BIAS_GELU>(g, acc, stg, n, mbase, lane);
+        case EPI_BIAS_DROP_RES: return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES>(g, acc, stg, n, mbase, lane);
+        case EPI_BIAS_TANH: return staged_epilogue_as<NIP, EPI_BIAS_TANH>(g, acc, stg, n, mbase, lane);
+        default: break;
+      }
+    } else if (!AKS && BKS) {
+      switch (g.epi) {
+        case EPI_MUL_DGELU: return staged_epilogue_as<NIP, EPI_MUL_DGELU>(g, acc, stg, n, mbase, lane);
+        case EPI_ADD_RES: return staged_epilogue_as<NIP, EPI_ADD_RES>(g, acc, stg, n, mbase, lane);
+        default: break;
+      }
+    }
+    staged_epilogue_as<NIP, EPI_PLAIN>(g, acc, stg, n, mbase, lane);
   }
 
   static __device__ __forceinline__ void run(const GemmArgs& g) {
@@ -257,40 +353,9 @@ struct GemmKernel {
       }
       return;
     }
-    DropKey dk = drop_key(g.rng);
-    // wave-private 32-row x 64-col fp32 staging, 16-B chunks XOR-swizzled by (row & 15)
-    char* stg = smem + wave * (32 * 256);
-#pragma unroll
-    for (int ip = 0; ip < FM / 2; ++ip) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = h * 16 + lm;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int chunk = (j * 4 + lg) ^ lm;
-          *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
-        }
-      }
-      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int n = n0 + wn * WTN + (lane & 7) * 8;
-#pragma unroll 1
-      for (int it = 0; it < 4; ++it) {  // not unrolled: the epilogue math is emitted once per row pair
-        const int row = it * 8 + (lane >> 3), jc = lane & 7;
-        const int key = row & 15;
-        const float4v lo = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
-        const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int m = m0 + wm * WTM + ip * 32 + row;
-        if (m < g.M && n < g.N) {
-          epilogue8(g, m, n, v, dk);
-          if (g.colsum) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cs[i] += v[i];
-          }
-        }
-      }
-      if (g.colsum) flush_colsum(g, n, n < g.N, cs, lane);
-    }
+    static_assert(FN == 4 && FM % 2 == 0, "staged epilogue shape");
+    staged_epilogue<FM / 2>(g, acc, smem + wave * (32 * 256), n0 + wn * WTN + (lane & 7) * 8,
+                            [&](int ip) { return m0 + wm * WTM + ip * 32; }, lane);
   }
 };
 

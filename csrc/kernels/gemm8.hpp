@@ -252,41 +252,11 @@ struct Gemm8 {
       }
       return;
     }
-    DropKey dk = drop_key(g.rng);
-    char* stg = smem + wave * (32 * 256);
-#pragma unroll
-    for (int ip = 0; ip < 4; ++ip) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = h * 16 + lm;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int chunk = (j * 4 + lg) ^ lm;
-          *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
-        }
-      }
-      float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      // staged column block jc = lane&7: n-half jc>>2, 8 columns at (jc&3)*8
-      const int n = n0 + ((lane & 7) >> 2) * 128 + wc * 32 + (lane & 3) * 8;
-#pragma unroll 1
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + (lane >> 3), jc = lane & 7;
-        const int key = row & 15;
-        const float4v lo = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
-        const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        // staged row = (ip&1)*32 + row of m-half (ip>>1)
-        const int m = m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32 + row;
-        if (m < g.M && n < g.N) {
-          Base::epilogue8(g, m, n, v, dk);
-          if (g.colsum) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cs[i] += v[i];
-          }
-        }
-      }
-      if (g.colsum) Base::flush_colsum(g, n, n < g.N, cs, lane);
-    }
+    // staged column block jc = lane&7: n-half jc>>2, 8 columns at (jc&3)*8; staged row block pair ip:
+    // m-half ip>>1, rows (ip&1)*32.. of the wave's 64
+    Base::template staged_epilogue<4>(g, acc, smem + wave * (32 * 256),
+                                      n0 + ((lane & 7) >> 2) * 128 + wc * 32 + (lane & 3) * 8,
+                                      [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, lane);
   }
 };
 

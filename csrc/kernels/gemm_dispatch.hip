@@ -59,7 +59,12 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
     g->splits = (ktiles + kt_per - 1) / kt_per;  // no empty split
     return pdt_gemm_tn(dtype, tile, g, stream);
   }
-  if (g->epi == PDT_EPI_SLAB_F32) return -5;
+  // each operand layout carries the epilogues of its role (forward: bias family; data gradient: GELU-grad
+  // multiply / residual add)
+  const int e = g->epi;
+  const bool fwd_epi = e == PDT_EPI_BIAS || e == PDT_EPI_BIAS_GELU || e == PDT_EPI_BIAS_DROP_RES || e == PDT_EPI_BIAS_TANH;
+  const bool dgrad_epi = e == PDT_EPI_MUL_DGELU || e == PDT_EPI_ADD_RES;
+  if (e != PDT_EPI_PLAIN && !(layout == PDT_GEMM_NT && fwd_epi) && !(layout == PDT_GEMM_NN && dgrad_epi)) return -5;
   return layout == PDT_GEMM_NT ? pdt_gemm_nt(dtype, tile, g, stream) : pdt_gemm_nn(dtype, tile, g, stream);
 }
 
