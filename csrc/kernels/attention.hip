@@ -1,9 +1,11 @@
 // Fused scaled-dot-product attention for BERT-class encoders on gfx950: head_dim 64, S <= 512, key padding
 // mask, dropout on the probabilities.  Forward keeps the whole key/value panel of one (batch, head) in LDS
 // (S=512: 2 x 64 KiB) and a full score row in registers, so there is no online-softmax rescale.
-// Backward recomputes the probabilities from the saved log-sum-exp in two kernels with no atomics:
-//   dQ kernel    : one wave = 16 query rows, sweeps the keys       (S^T, dP^T -> dS^T -> dQ^T)
-//   dK/dV kernel : one wave = 16 keys,       sweeps the queries    (S, dP -> P, dS -> dV^T, dK^T)
+// Backward recomputes the probabilities from the saved log-sum-exp in two sweeps with no atomics on dQ/dK/dV:
+//   dQ sweep    : one wave = 16 query rows, sweeps the keys       (S^T, dP^T -> dS^T -> dQ^T)
+//   dK/dV sweep : one wave = 16 keys,       sweeps the queries    (S, dP -> P, dS -> dV^T, dK^T)
+// For S <= 128 both sweeps run in ONE kernel on shared LDS images (and the QKV bias gradient is reduced in
+// it); longer sequences use one kernel per sweep.
 // Products are arranged "key on the register axis" so that an accumulator tile is directly the B operand
 // of the next MFMA (16x16x32, k index permuted consistently on both operands), and the other operand is
 // fetched from a row-major LDS image with ds_read_b64_tr_b16.  One XOR-swizzled image layout
@@ -352,6 +354,205 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward, S <= 128
+// One workgroup owns a whole (batch, head): Q, K, V and dO images (4 x 16 KiB) are loaded once, wave w
+// first produces dQ for query rows 16w.. (keys on the sweep axis), then dK/dV for keys 16w.. (queries on the
+// sweep axis).  Compared with the two-kernel path every input is read from HBM once instead of twice, delta
+// never leaves LDS, and the column sums of dQ/dK/dV (the QKV bias gradient) are reduced here - 16-lane
+// shuffles, LDS float atomics across the 8 waves, then 192 global atomics per workgroup into `dbias`.
+template <typename T>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
+  constexpr int SMAX = 128, NPB = SMAX / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qimg = smem;
+  char* kimg = smem + SMAX * 128;
+  char* vimg = smem + 2 * SMAX * 128;
+  char* dimg = smem + 3 * SMAX * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * SMAX * 128);
+  float* del_s = lse_s + SMAX;
+  float* mbias = del_s + SMAX;
+  float* cs = mbias + SMAX;  // [3][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
+  const int S = a.S, ld = 3 * a.H;
+  const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
+  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
+  const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
+  const int kvl = min(a.kv_len[b], S);
+  const int npb = (kvl + 31) >> 5, nqb = (S + 31) >> 5;
+  load_image<T>(qimg, base, ld, S, nqb * 32, tid);
+  load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
+  load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
+  load_image<T>(dimg, dob, a.H, S, nqb * 32, tid);
+  for (int i = tid; i < SMAX; i += ATT_THREADS) {
+    mbias[i] = (i < S && a.mask[(size_t)b * S + i] != 0) ? 0.f : -INFINITY;
+    lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
+  }
+  if (tid < 192) cs[tid] = 0.f;
+  const int lm = lane & 15, g = lane >> 4;
+  const int r0 = wave * 16;  // this wave's query rows in the dQ phase, its keys in the dK/dV phase
+  {
+    // delta = rowsum(dO * O) of the wave's 16 query rows
+    float d = 0.f;
+    const int q = r0 + lm;
+    if (q < S) {
+      const short8 df0 = gfrag<T>(dob, q, a.H, 0, lane), df1 = gfrag<T>(dob, q, a.H, 1, lane);
+      const short8 of0 = gfrag<T>(ob, q, a.H, 0, lane), of1 = gfrag<T>(ob, q, a.H, 1, lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        d += Half16<T>::to_f(df0[j]) * Half16<T>::to_f(of0[j]) + Half16<T>::to_f(df1[j]) * Half16<T>::to_f(of1[j]);
+    }
+    d = quad_sum(d);
+    if (g == 0) del_s[q] = d;
+  }
+  __syncthreads();
+  const DropKey dk = drop_key(a.rng);
+
+  // sum over the 16 rows a wave holds (lane&15), result valid in lanes with (lane&15)==0
+  auto rows16 = [](float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+  };
+
+  // ---- dQ for query rows r0..r0+15
+  if (r0 < S) {
+    const int q = r0 + lm;
+    const short8 qf0 = row_frag(qimg, r0, 0, lane), qf1 = row_frag(qimg, r0, 1, lane);
+    const short8 df0 = row_frag(dimg, r0, 0, lane), df1 = row_frag(dimg, r0, 1, lane);
+    const float lse = lse_s[q], delta = del_s[q];
+    float4v dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      if (pb < npb) {
+        float4v ds[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const int kb16 = pb * 32 + hb * 16;
+          float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = Half16<T>::mfma(row_frag(kimg, kb16, 0, lane), qf0, sc);
+          sc = Half16<T>::mfma(row_frag(kimg, kb16, 1, lane), qf1, sc);
+          dp = Half16<T>::mfma(row_frag(vimg, kb16, 0, lane), df0, dp);
+          dp = Half16<T>::mfma(row_frag(vimg, kb16, 1, lane), df1, dp);
+          const float4v mb = *reinterpret_cast<const float4v*>(mbias + kb16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(sc[r] * a.scale + mb[r] - lse);
+            float d = dp[r];
+            if (a.drop_thr != 0) d = attn_keep(dk, bh, q, kb16 + 4 * g + r, a.drop_thr) ? d * a.drop_scale : 0.f;
+            ds[hb][r] = q < S ? p * (d - delta) * a.scale : 0.f;
+          }
+        }
+        const short8 dsf = pack_pair<T>(ds[0], ds[1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(kimg, pb * 32, db, lane), dsf, dq[db]);
+      }
+    }
+    if (q < S) {
+      T* out = (T*)a.dqkv + ((size_t)b * S + q) * ld + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        short4v pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pk[r] = Half16<T>::from_f(dq[db][r]);
+        *reinterpret_cast<short4v*>(out + db * 16 + 4 * g) = pk;
+      }
+    }
+    if (dbias) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = rows16(dq[db][r]);
+          if (lm == 0) atomicAdd(cs + db * 16 + 4 * g + r, v);
+        }
+    }
+  }
+
+  // ---- dK, dV for keys r0..r0+15 (keys at or beyond kv_len receive exactly zero gradient)
+  {
+    const int key = r0 + lm;
+    float4v dk_[4], dv_[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
+    if (r0 < kvl) {
+      const short8 kf0 = row_frag(kimg, r0, 0, lane), kf1 = row_frag(kimg, r0, 1, lane);
+      const short8 vf0 = row_frag(vimg, r0, 0, lane), vf1 = row_frag(vimg, r0, 1, lane);
+      const float mb = mbias[key];
+#pragma unroll
+      for (int qb = 0; qb < NPB; ++qb) {
+        if (qb < nqb) {
+          float4v pp[2], ds[2];
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            const int q16 = qb * 32 + hb * 16;
+            float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sc = Half16<T>::mfma(row_frag(qimg, q16, 0, lane), kf0, sc);
+            sc = Half16<T>::mfma(row_frag(qimg, q16, 1, lane), kf1, sc);
+            dp = Half16<T>::mfma(row_frag(dimg, q16, 0, lane), vf0, dp);
+            dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
+            const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
+            const float4v de = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int q = q16 + 4 * g + r;
+              float p = __expf(sc[r] * a.scale + mb - ls[r]);
+              if (q >= S) p = 0.f;
+              float d = dp[r], pd = p;
+              if (a.drop_thr != 0) {
+                const bool keep = attn_keep(dk, bh, q, key, a.drop_thr);
+                d = keep ? d * a.drop_scale : 0.f;
+                pd = keep ? p * a.drop_scale : 0.f;
+              }
+              pp[hb][r] = pd;
+              ds[hb][r] = p * (d - de[r]) * a.scale;
+            }
+          }
+          const short8 pf = pack_pair<T>(pp[0], pp[1]);
+          const short8 dsf = pack_pair<T>(ds[0], ds[1]);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            dv_[db] = Half16<T>::mfma(tr_frag(dimg, qb * 32, db, lane), pf, dv_[db]);
+            dk_[db] = Half16<T>::mfma(tr_frag(qimg, qb * 32, db, lane), dsf, dk_[db]);
+          }
+        }
+      }
+    }
+    if (key < S) {
+      T* outk = (T*)a.dqkv + ((size_t)b * S + key) * ld + a.H + h * HD;
+      T* outv = outk + a.H;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        short4v pk, pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pk[r] = Half16<T>::from_f(dk_[db][r]); pv[r] = Half16<T>::from_f(dv_[db][r]); }
+        *reinterpret_cast<short4v*>(outk + db * 16 + 4 * g) = pk;
+        *reinterpret_cast<short4v*>(outv + db * 16 + 4 * g) = pv;
+      }
+    }
+    if (dbias && r0 < kvl) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vk = rows16(key < S ? dk_[db][r] : 0.f), vv = rows16(key < S ? dv_[db][r] : 0.f);
+          if (lm == 0) {
+            atomicAdd(cs + 64 + db * 16 + 4 * g + r, vk);
+            atomicAdd(cs + 128 + db * 16 + 4 * g + r, vv);
+          }
+        }
+    }
+  }
+  if (dbias) {
+    __syncthreads();
+    if (tid < 192) atomicAdd(dbias + (tid >> 6) * a.H + h * HD + (tid & 63), cs[tid]);
+  }
+}
+
 template <typename KernT>
 static int launch_attn(KernT kern, const AttnArgs& a, int smax, hipStream_t stream) {
   const size_t lds = (size_t)2 * smax * 128 + (size_t)2 * smax * sizeof(float);
@@ -391,16 +592,30 @@ extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, con
   return dtype == PDT_F16 ? attn_dispatch<_Float16>(0, a, (hipStream_t)stream) : attn_dispatch<__bf16>(0, a, (hipStream_t)stream);
 }
 
+template <typename T>
+static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) {
+  const size_t lds = (size_t)4 * 128 * 128 + (size_t)(3 * 128 + 192) * sizeof(float);
+  auto kern = attn_bwd_fused128_kernel<T>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.A), dim3(ATT_THREADS), lds, stream, a, dbias);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_attn_bwd_fuses_dbias(int S) { return S <= 128 ? 1 : 0; }
+
 extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const void* ctx,
-                            const void* dctx, const float* lse, float* delta, void* dqkv, int B, int S, int A,
-                            float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
+                            const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias, int B, int S,
+                            int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
   if (int e = check_attn(B, S, A)) return e;
+  if (dbias && !pdt_attn_bwd_fuses_dbias(S)) return -3;
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.octx = ctx; a.dctx = dctx; a.lse = const_cast<float*>(lse);
   a.delta = delta; a.dqkv = dqkv;
   a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = 0.125f;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
   hipStream_t s = (hipStream_t)stream;
+  if (S <= 128) return dtype == PDT_F16 ? launch_fused128<_Float16>(a, dbias, s) : launch_fused128<__bf16>(a, dbias, s);
   int e = dtype == PDT_F16 ? attn_dispatch<_Float16>(1, a, s) : attn_dispatch<__bf16>(1, a, s);
   if (e) return e;
   return dtype == PDT_F16 ? attn_dispatch<_Float16>(2, a, s) : attn_dispatch<__bf16>(2, a, s);

@@ -230,11 +230,15 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // attention core
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
+  // the short-sequence backward kernel also reduces the QKV bias gradient (atomic adds into gr[1])
+  const bool fused_db = pdt_attn_bwd_fuses_dbias((int)S) != 0;
+  if (fused_db && !accumulate) gr[1].zero_();
   check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
-                     dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)S,
-                     (int)A, keep_scale(p_attn), thr16(p_attn), make_rng(rng_state, micro, site + 0), cur_stream()),
+                     dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
+                     fused_db ? gr[1].data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
+                     thr16(p_attn), make_rng(rng_state, micro, site + 0), cur_stream()),
         "attn_bwd");
-  colsum_into(dqkv, gr[1], accumulate);
+  if (!fused_db) colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
   Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
   Tensor dx = gemm_nn(dqkv, w[0], e_add2);
@@ -461,7 +465,7 @@ std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Ten
 }
 Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, const Tensor& ctx, const Tensor& dctx,
                    const Tensor& lse, int64_t B, int64_t S, int64_t A, const c10::optional<Tensor>& rng_state, double p,
-                   int64_t micro, int64_t site) {
+                   int64_t micro, int64_t site, c10::optional<Tensor> dbias) {
   DeviceGuard guard(qkv.device());
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
@@ -469,8 +473,9 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
   PdtRng rng{nullptr, 0, 0};
   if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
   check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
-                     dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(), (int)B, (int)S,
-                     (int)A, keep_scale(p), thr16(p), rng, cur_stream()), "attn_bwd");
+                     dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
+                     dbias.has_value() ? dbias->data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p),
+                     thr16(p), rng, cur_stream()), "attn_bwd");
   return dqkv;
 }
 
@@ -501,7 +506,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("op_layernorm_fwd", &op_layernorm_fwd);
   m.def("op_layernorm_bwd", &op_layernorm_bwd);
   m.def("op_attn_fwd", &op_attn_fwd);
-  m.def("op_attn_bwd", &op_attn_bwd);
+  m.def("op_attn_bwd", &op_attn_bwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("ctx"), py::arg("dctx"),
+        py::arg("lse"), py::arg("B"), py::arg("S"), py::arg("A"), py::arg("rng_state"), py::arg("p"), py::arg("micro"),
+        py::arg("site"), py::arg("dbias") = py::none());
+  m.def("attn_bwd_fuses_dbias", [](int64_t S) { return pdt_attn_bwd_fuses_dbias((int)S) != 0; });
   bind_reducer(m);
   bind_wordpiece(m);
 }

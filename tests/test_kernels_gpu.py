@@ -209,8 +209,12 @@ def test_attention_fwd_bwd(dtype, B, S, A):
     # padded query rows carry no gradient in a real model
     dctx = dctx * mask.view(B * S, 1).to(dtype)
     ref.backward(dctx.float())
-    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, None, 0.0, 0, 0)
+    fused = C().attn_bwd_fuses_dbias(S)
+    dbias = torch.full((3 * H,), 0.5, device="cuda") if fused else None
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, None, 0.0, 0, 0, dbias)
     assert rel_err(dqkv, qf.grad) < (3e-2 if dtype == torch.bfloat16 else 6e-3)
+    if fused:  # the short-sequence kernel adds the QKV bias gradient (column sums of dqkv) into `dbias`
+        assert rel_err(dbias - 0.5, qf.grad.sum(0)) < (2e-2 if dtype == torch.bfloat16 else 5e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -249,7 +253,9 @@ def test_attention_general_mask_and_dropout(dtype):
     torch.testing.assert_close(ctx.float(), ref, rtol=3e-2, atol=2e-2)
     dctx = torch.randn(B * S, H, device="cuda").to(dtype)
     ref.backward(dctx.float())
-    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, st, p, 1, 4)
+    dbias = torch.zeros(3 * H, device="cuda")
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, st, p, 1, 4, dbias)
+    assert rel_err(dbias, dqkv.float().sum(0)) < 5e-3
     # keys that are masked get exactly zero gradient
     gk = dqkv.view(B, S, 3, A, 64)[:, :, 1:]
     assert gk[mask == 0].abs().max().item() == 0
