@@ -36,17 +36,25 @@ struct AttnArgs {
   RngArgs rng;
 };
 
-// per-element dropout decision for the probabilities: a function of (seed, offset, site, micro, b*A+h, q, key)
-// only, so the three kernels agree whatever their lane mapping is.
+// Dropout decision for probability (bh, q, key): a function of (seed, offset, site, micro, b*A+h, q, key) only,
+// so every kernel agrees whatever its lane mapping is.  It is split in two so that the per-element cost is one
+// 32-bit multiply: a strongly mixed 32-bit seed per query row (computed once per row - in the dK/dV sweeps it
+// is staged in LDS), and per element  x = (row_seed ^ key * GOLD) * MIX,  keep <=> high16(x) >= thr.
+// key * GOLD is a Weyl sequence over the keys; an unrolled sweep forms it with one add per element.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ bool attn_keep(const DropKey& dk, uint32_t bh, uint32_t q, uint32_t key, uint32_t thr) {
-  uint32_t x = lowbias32((q * 512u + key) ^ dk.key.x);
-  x = lowbias32(x ^ (bh * 0x9E3779B9u) ^ dk.key.y ^ (dk.stream * 0x85EBCA6Bu) ^ (dk.micro * 0xC2B2AE35u));
-  return (x >> 16) >= thr;
+constexpr uint32_t ATT_GOLD = 0x9E3779B9u, ATT_MIX = 0x85EBCA6Bu;
+__device__ __forceinline__ uint32_t attn_row_seed(const DropKey& dk, uint32_t bh, uint32_t q) {
+  uint32_t x = lowbias32(q ^ dk.key.x);
+  return lowbias32(x ^ (bh * 0x9E3779B9u) ^ dk.key.y ^ (dk.stream * 0x85EBCA6Bu) ^ (dk.micro * 0xC2B2AE35u));
 }
+// thr_hi = drop threshold << 16 (see attn_thr_hi); kmul = key * ATT_GOLD
+__device__ __forceinline__ bool attn_keep(uint32_t row_seed, uint32_t kmul, uint32_t thr_hi) {
+  return (row_seed ^ kmul) * ATT_MIX >= thr_hi;
+}
+__device__ __forceinline__ uint32_t attn_thr_hi(uint32_t thr) { return (thr > 65535u ? 65535u : thr) << 16; }
 
 // cooperative load of `nrows_pad` rows of 64 16-bit values (row stride `stride` elements) into an image
 template <typename T>
@@ -153,7 +161,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = mx + __logf(l);
 
-  DropKey dk = drop_key(a.rng);
+  const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
+  const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   float4v o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) {
           float p = s[2 * pb + hb][r] * inv;
           if (a.drop_thr != 0)
-            p = attn_keep(dk, bh, q, pb * 32 + hb * 16 + 4 * g + r, a.drop_thr) ? p * a.drop_scale : 0.f;
+            p = attn_keep(rseed, kmul0 + (uint32_t)(pb * 32 + hb * 16 + r) * ATT_GOLD, thr_hi) ? p * a.drop_scale : 0.f;
           s[2 * pb + hb][r] = p;
         }
       }
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     if (g == 0 && q < S) a.delta[(size_t)bh * S + q] = delta;
   }
   const float lse = a.lse[(size_t)bh * S + qc];
-  DropKey dk = drop_key(a.rng);
+  const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
+  const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   float4v dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const float p = __expf(sc[r] * a.scale + mb[r] - lse);
         float d = dp[r];
-        if (a.drop_thr != 0) d = attn_keep(dk, bh, q, kb16 + 4 * g + r, a.drop_thr) ? d * a.drop_scale : 0.f;
+        if (a.drop_thr != 0) d = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? d * a.drop_scale : 0.f;
         ds[hb][r] = p * (d - delta) * a.scale;
       }
     }
@@ -273,12 +283,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   char* dimg = smem + SMAX * 128;
   float* lse_s = reinterpret_cast<float*>(smem + 2 * SMAX * 128);
   float* del_s = lse_s + SMAX;
+  uint32_t* seed_s = reinterpret_cast<uint32_t*>(del_s + SMAX);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
   const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
   const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
   const int nqb = (S + 31) >> 5;  // 32-row query blocks
+  const DropKey dk = drop_key(a.rng);
   const int kvl = min(a.kv_len[b], S);
   const int k0 = blockIdx.y * ATT_ROWS + wave * 16;
   // keys at or beyond kv_len receive exactly zero gradient: the block only has to write zeros
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
       lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
       del_s[i] = i < S ? a.delta[(size_t)bh * S + i] : 0.f;
+      seed_s[i] = attn_row_seed(dk, bh, i);
     }
   }
   __syncthreads();
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     const short8 kf0 = gfrag<T>(base + a.H, kc, ld, 0, lane), kf1 = gfrag<T>(base + a.H, kc, ld, 1, lane);
     const short8 vf0 = gfrag<T>(base + 2 * a.H, kc, ld, 0, lane), vf1 = gfrag<T>(base + 2 * a.H, kc, ld, 1, lane);
     const float mb = (key < S && a.mask[(size_t)b * S + kc] != 0) ? 0.f : -INFINITY;
-    DropKey dk = drop_key(a.rng);
+    const uint32_t kmul = (uint32_t)key * ATT_GOLD, thr_hi = attn_thr_hi(a.drop_thr);
 #pragma unroll 1
     for (int qb = 0; qb < nqb; ++qb) {
       float4v pp[2], ds[2];
@@ -316,6 +329,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
         dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
         const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
         const float4v de = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g);
+        const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = q16 + 4 * g + r;
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
           if (q >= S) p = 0.f;
           float d = dp[r], pd = p;
           if (a.drop_thr != 0) {
-            const bool keep = attn_keep(dk, bh, q, key, a.drop_thr);
+            const bool keep = attn_keep(sd[r], kmul, thr_hi);
             d = keep ? d * a.drop_scale : 0.f;
             pd = keep ? p * a.drop_scale : 0.f;
           }
@@ -372,6 +386,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
   float* del_s = lse_s + SMAX;
   float* mbias = del_s + SMAX;
   float* cs = mbias + SMAX;  // [3][64]
+  uint32_t* seed_s = reinterpret_cast<uint32_t*>(cs + 192);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
@@ -380,6 +395,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
   const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
   const int kvl = min(a.kv_len[b], S);
   const int npb = (kvl + 31) >> 5, nqb = (S + 31) >> 5;
+  const DropKey dk = drop_key(a.rng);
+  const uint32_t thr_hi = attn_thr_hi(a.drop_thr);
   load_image<T>(qimg, base, ld, S, nqb * 32, tid);
   load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
   load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
@@ -387,6 +404,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
   for (int i = tid; i < SMAX; i += ATT_THREADS) {
     mbias[i] = (i < S && a.mask[(size_t)b * S + i] != 0) ? 0.f : -INFINITY;
     lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
+    seed_s[i] = attn_row_seed(dk, bh, i);
   }
   if (tid < 192) cs[tid] = 0.f;
   const int lm = lane & 15, g = lane >> 4;
@@ -406,7 +424,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
     if (g == 0) del_s[q] = d;
   }
   __syncthreads();
-  const DropKey dk = drop_key(a.rng);
 
   // sum over the 16 rows a wave holds (lane&15), result valid in lanes with (lane&15)==0
   auto rows16 = [](float v) {
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
     const short8 qf0 = row_frag(qimg, r0, 0, lane), qf1 = row_frag(qimg, r0, 1, lane);
     const short8 df0 = row_frag(dimg, r0, 0, lane), df1 = row_frag(dimg, r0, 1, lane);
     const float lse = lse_s[q], delta = del_s[q];
+    const uint32_t rseed = seed_s[q], kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
     float4v dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
           for (int r = 0; r < 4; ++r) {
             const float p = __expf(sc[r] * a.scale + mb[r] - lse);
             float d = dp[r];
-            if (a.drop_thr != 0) d = attn_keep(dk, bh, q, kb16 + 4 * g + r, a.drop_thr) ? d * a.drop_scale : 0.f;
+            if (a.drop_thr != 0) d = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? d * a.drop_scale : 0.f;
             ds[hb][r] = q < S ? p * (d - delta) * a.scale : 0.f;
           }
         }
@@ -483,6 +501,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
       const short8 kf0 = row_frag(kimg, r0, 0, lane), kf1 = row_frag(kimg, r0, 1, lane);
       const short8 vf0 = row_frag(vimg, r0, 0, lane), vf1 = row_frag(vimg, r0, 1, lane);
       const float mb = mbias[key];
+      const uint32_t kmul = (uint32_t)key * ATT_GOLD;
 #pragma unroll
       for (int qb = 0; qb < NPB; ++qb) {
         if (qb < nqb) {
@@ -497,6 +516,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
             dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
             const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
             const float4v de = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g);
+            const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int q = q16 + 4 * g + r;
@@ -504,7 +524,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
               if (q >= S) p = 0.f;
               float d = dp[r], pd = p;
               if (a.drop_thr != 0) {
-                const bool keep = attn_keep(dk, bh, q, key, a.drop_thr);
+                const bool keep = attn_keep(sd[r], kmul, thr_hi);
                 d = keep ? d * a.drop_scale : 0.f;
                 pd = keep ? p * a.drop_scale : 0.f;
               }
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
 
 template <typename KernT>
 static int launch_attn(KernT kern, const AttnArgs& a, int smax, hipStream_t stream) {
-  const size_t lds = (size_t)2 * smax * 128 + (size_t)2 * smax * sizeof(float);
+  const size_t lds = (size_t)2 * smax * 128 + (size_t)3 * smax * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a);
@@ -594,7 +614,7 @@ extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, con
 
 template <typename T>
 static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) {
-  const size_t lds = (size_t)4 * 128 * 128 + (size_t)(3 * 128 + 192) * sizeof(float);
+  const size_t lds = (size_t)4 * 128 * 128 + (size_t)(4 * 128 + 192) * sizeof(float);
   auto kern = attn_bwd_fused128_kernel<T>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;

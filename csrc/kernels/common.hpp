@@ -12,6 +12,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short short4r __attribute__((__vector_size__(4 * sizeof(short))));

@@ -247,6 +247,13 @@ def test_attention_general_mask_and_dropout(dtype):
     frac = keepmask[valid].mean().item()
     assert abs(frac - (1 - p)) < 0.02
     torch.testing.assert_close(pd, pref * keepmask / (1 - p), rtol=3e-2, atol=3e-3)
+    # the decisions of neighbouring keys / neighbouring query rows / neighbouring heads are uncorrelated
+    def corr(x, y, ok):
+        x, y = x[ok] - x[ok].mean(), y[ok] - y[ok].mean()
+        return (x * y).mean().item() / (x.std().item() * y.std().item() + 1e-12)
+    assert abs(corr(keepmask[..., :-1], keepmask[..., 1:], valid[..., :-1] & valid[..., 1:])) < 0.02
+    assert abs(corr(keepmask[:, :, :-1], keepmask[:, :, 1:], valid[:, :, :-1] & valid[:, :, 1:])) < 0.02
+    assert abs(corr(keepmask[:, :-1], keepmask[:, 1:], valid[:, :-1] & valid[:, 1:])) < 0.02
     # backward with the same dropout mask
     qf = qkv.float().requires_grad_()
     ref, _ = ref_attention(qf, mask, B, S, A, keepmask, 1 - p)
