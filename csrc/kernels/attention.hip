@@ -15,6 +15,7 @@
 namespace pdt {
 
 constexpr int HD = 64;       // head dim
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int ATT_WAVES = 8;  // waves per workgroup: 8 x 16 = 128 query rows (or keys) share one K/V (or Q/dO) image
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int ATT_ROWS = ATT_WAVES * 16;
@@ -39,20 +40,20 @@ struct AttnArgs {
 // Dropout decision for probability (bh, q, key): a function of (seed, offset, site, micro, b*A+h, q, key) only,
 // so every kernel agrees whatever its lane mapping is.  It is split in two so that the per-element cost is one
 // 32-bit multiply: a strongly mixed 32-bit seed per query row (computed once per row - in the dK/dV sweeps it
-// is staged in LDS), and per element  x = (row_seed ^ key * GOLD) * MIX,  keep <=> high16(x) >= thr.
+// is staged in LDS), and per element  x = low24(row_seed ^ key * GOLD) * MIX24,  keep <=> x[31:16] >= thr.
 // key * GOLD is a Weyl sequence over the keys; an unrolled sweep forms it with one add per element.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-constexpr uint32_t ATT_GOLD = 0x9E3779B9u, ATT_MIX = 0x85EBCA6Bu;
+constexpr uint32_t ATT_GOLD = 0x9E3779B9u, ATT_MIX = 0xEBCA6Bu;
 __device__ __forceinline__ uint32_t attn_row_seed(const DropKey& dk, uint32_t bh, uint32_t q) {
   uint32_t x = lowbias32(q ^ dk.key.x);
   return lowbias32(x ^ (bh * 0x9E3779B9u) ^ dk.key.y ^ (dk.stream * 0x85EBCA6Bu) ^ (dk.micro * 0xC2B2AE35u));
 }
 // thr_hi = drop threshold << 16 (see attn_thr_hi); kmul = key * ATT_GOLD
 __device__ __forceinline__ bool attn_keep(uint32_t row_seed, uint32_t kmul, uint32_t thr_hi) {
-  return (row_seed ^ kmul) * ATT_MIX >= thr_hi;
+  return __umul24(row_seed ^ kmul, ATT_MIX) >= thr_hi;  // 24 x 24 -> low 32 bits: a full-rate multiply
 }
 __device__ __forceinline__ uint32_t attn_thr_hi(uint32_t thr) { return (thr > 65535u ? 65535u : thr) << 16; }
 
@@ -64,6 +65,33 @@ __device__ __forceinline__ void load_image(char* img, const T* src, int stride, 
     short8 v = short8{0, 0, 0, 0, 0, 0, 0, 0};
     if (row < nvalid) v = *reinterpret_cast<const short8*>(src + (size_t)row * stride + c * 8);
     *reinterpret_cast<short8*>(img + row * 128 + ((c ^ (row & 6)) << 4)) = v;
+  }
+}
+// The same for NIMG images at once: all global loads of a pass (2 chunks per image and thread) are in flight
+// before the first LDS write, so a workgroup pays one memory latency per pass instead of one per chunk.
+template <typename T, int NIMG>
+__device__ __forceinline__ void load_images(char* const (&img)[NIMG], const T* const (&src)[NIMG], const int (&stride)[NIMG],
+                                            const int (&nvalid)[NIMG], const int (&nrows_pad)[NIMG], int tid) {
+  int maxpad = 0;
+#pragma unroll
+  for (int i = 0; i < NIMG; ++i) maxpad = max(maxpad, nrows_pad[i]);
+  for (int base = 0; base < maxpad * 8; base += 2 * ATT_THREADS) {
+    short8 v[NIMG][2];
+#pragma unroll
+    for (int i = 0; i < NIMG; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = base + u * ATT_THREADS + tid, row = idx >> 3, c = idx & 7;
+        v[i][u] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < nvalid[i] && row < nrows_pad[i]) v[i][u] = *reinterpret_cast<const short8*>(src[i] + (size_t)row * stride[i] + c * 8);
+      }
+#pragma unroll
+    for (int i = 0; i < NIMG; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = base + u * ATT_THREADS + tid, row = idx >> 3, c = idx & 7;
+        if (row < nrows_pad[i]) *reinterpret_cast<short8*>(img[i] + row * 128 + ((c ^ (row & 6)) << 4)) = v[i][u];
+      }
   }
 }
 // rows x0..x0+15 as an MFMA A operand: lane -> row x0+(lane&15), k = 8*(lane>>4)+j of k-step ks (k = head dim)
@@ -159,7 +187,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   }
   l = quad_sum(l);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
-  if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = mx + __logf(l);
+  // a row whose keys are all masked has no probability mass: lse = +inf makes every recomputed p exactly 0
+  if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = l > 0.f ? mx + __logf(l) : INFINITY;
 
   const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
@@ -369,27 +398,69 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward, S <= 128
-// One workgroup owns a whole (batch, head): Q, K, V and dO images (4 x 16 KiB) are loaded once, wave w
+// One workgroup owns a whole (batch, head): Q, K, V and dO images (4 x 16 KiB, LDS-DMA) are loaded once, wave w
 // first produces dQ for query rows 16w.. (keys on the sweep axis), then dK/dV for keys 16w.. (queries on the
 // sweep axis).  Compared with the two-kernel path every input is read from HBM once instead of twice, delta
-// never leaves LDS, and the column sums of dQ/dK/dV (the QKV bias gradient) are reduced here - 16-lane
-// shuffles, LDS float atomics across the 8 waves, then 192 global atomics per workgroup into `dbias`.
+// never leaves LDS, and the column sums of dQ/dK/dV (the QKV bias gradient) are reduced here without atomics:
+// DPP row reductions over the 16 rows of a wave, one LDS slot per wave, then the workgroup writes its 192
+// sums to dbias_partial[b][3H] (summed over b afterwards by the deterministic column-sum finisher).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x128>(v);  // row_ror:8
+  v += dpp_f<0x124>(v);  // row_ror:4
+  v += dpp_f<0x122>(v);  // row_ror:2
+  v += dpp_f<0x121>(v);  // row_ror:1
+  return v;
+}
+// LDS-DMA fill of one 128-row image (2 x 1 KiB pieces per wave): the swizzle is applied on the per-lane SOURCE
+// address because a DMA write is lane-linear; rows in [nvalid, 128) read out of bounds and arrive as zeros.
 template <typename T>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
+__device__ __forceinline__ void dma_image128(char* img, const T* src, int stride, int nvalid, int tid, int wave) {
+  const uint32_t bytes = (uint32_t)(((size_t)(nvalid - 1) * stride + HD) * 2);
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, bytes, 0x00020000);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = u * ATT_THREADS + tid, row = idx >> 3, c = (idx & 7) ^ (row & 6);
+    const uint32_t off = row < nvalid ? ((uint32_t)row * stride + c * 8) * 2u : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(img + (u * ATT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
+  }
+}
+
+#ifndef PDT_ATT_FUSED_WAVES_EU  // minimum waves per SIMD the register allocation of the fused kernel must allow
+#define PDT_ATT_FUSED_WAVES_EU 4
+#endif
+template <typename T>
+__global__ __launch_bounds__(ATT_THREADS) __attribute__((amdgpu_waves_per_eu(PDT_ATT_FUSED_WAVES_EU, 8)))
+void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   constexpr int SMAX = 128, NPB = SMAX / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* qimg = smem;
-  char* kimg = smem + SMAX * 128;
-  char* vimg = smem + 2 * SMAX * 128;
-  char* dimg = smem + 3 * SMAX * 128;
+  // four 16-KiB images, K and V for the dQ sweep, Q and dO for the dK/dV sweep: 2 workgroups per CU.  (Re-using
+  // two images for both sweeps fits 4 workgroups in LDS, but the dK/dV sweep needs ~90 VGPRs, so the register
+  // file allows no more than 2 anyway - measured slower.)
+  char* img0 = smem;
+  char* img1 = smem + SMAX * 128;
+  char* img2 = smem + 2 * SMAX * 128;
+  char* img3 = smem + 3 * SMAX * 128;
   float* lse_s = reinterpret_cast<float*>(smem + 4 * SMAX * 128);
   float* del_s = lse_s + SMAX;
   float* mbias = del_s + SMAX;
-  float* cs = mbias + SMAX;  // [3][64]
-  uint32_t* seed_s = reinterpret_cast<uint32_t*>(cs + 192);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* seed_s = reinterpret_cast<uint32_t*>(mbias + SMAX);
+  float* csq = reinterpret_cast<float*>(seed_s + SMAX);  // [ATT_WAVES][64] dQ column sums per wave
+  float* cskv = csq + ATT_WAVES * 64;                    // [ATT_WAVES][128] dK|dV column sums per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
+#ifdef PDT_ATT_STAMP  // phase time stamps of wave 0 (100 MHz counter) into the otherwise unused delta buffer
+#define PDT_STAMP(i) do { if (tid == 0) a.delta[(size_t)bh * S + (i)] = (float)(wall_clock64() & 0xFFFFFF); } while (0)
+#else
+#define PDT_STAMP(i) do { } while (0)
+#endif
+  PDT_STAMP(0);
   const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
   const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
   const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
@@ -397,49 +468,50 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
   const int npb = (kvl + 31) >> 5, nqb = (S + 31) >> 5;
   const DropKey dk = drop_key(a.rng);
   const uint32_t thr_hi = attn_thr_hi(a.drop_thr);
-  load_image<T>(qimg, base, ld, S, nqb * 32, tid);
-  load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
-  load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
-  load_image<T>(dimg, dob, a.H, S, nqb * 32, tid);
+  const int lm = lane & 15, g = lane >> 4;
+  const float k2 = a.scale * LOG2E;  // scores -> log2 domain
+  const bool drop = a.drop_thr != 0;
+  const int r0 = wave * 16;  // this wave's query rows in the dQ sweep, its keys in the dK/dV sweep
+
+  dma_image128<T>(img0, base + a.H, ld, S, tid, wave);      // K
+  dma_image128<T>(img1, base + 2 * a.H, ld, S, tid, wave);  // V
+  dma_image128<T>(img2, base, ld, S, tid, wave);            // Q
+  dma_image128<T>(img3, dob, a.H, S, tid, wave);            // dO
   for (int i = tid; i < SMAX; i += ATT_THREADS) {
     mbias[i] = (i < S && a.mask[(size_t)b * S + i] != 0) ? 0.f : -INFINITY;
-    lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
+    // log2-domain lse; +inf for the padding rows makes their recomputed probabilities exactly 0
+    lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] * LOG2E : INFINITY;
     seed_s[i] = attn_row_seed(dk, bh, i);
   }
-  if (tid < 192) cs[tid] = 0.f;
-  const int lm = lane & 15, g = lane >> 4;
-  const int r0 = wave * 16;  // this wave's query rows in the dQ phase, its keys in the dK/dV phase
+  // the wave's own query rows of Q and dO straight from global memory (B-operand fragments), and
+  // delta = rowsum(dO * O)
+  short8 qf0, qf1, df0, df1;
   {
-    // delta = rowsum(dO * O) of the wave's 16 query rows
+    const int q = r0 + lm, qc = min(q, S - 1);
+    qf0 = gfrag<T>(base, qc, ld, 0, lane); qf1 = gfrag<T>(base, qc, ld, 1, lane);
+    df0 = gfrag<T>(dob, qc, a.H, 0, lane); df1 = gfrag<T>(dob, qc, a.H, 1, lane);
+    const short8 of0 = gfrag<T>(ob, qc, a.H, 0, lane), of1 = gfrag<T>(ob, qc, a.H, 1, lane);
     float d = 0.f;
-    const int q = r0 + lm;
-    if (q < S) {
-      const short8 df0 = gfrag<T>(dob, q, a.H, 0, lane), df1 = gfrag<T>(dob, q, a.H, 1, lane);
-      const short8 of0 = gfrag<T>(ob, q, a.H, 0, lane), of1 = gfrag<T>(ob, q, a.H, 1, lane);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        d += Half16<T>::to_f(df0[j]) * Half16<T>::to_f(of0[j]) + Half16<T>::to_f(df1[j]) * Half16<T>::to_f(of1[j]);
-    }
+    for (int j = 0; j < 8; ++j)
+      d += Half16<T>::to_f(df0[j]) * Half16<T>::to_f(of0[j]) + Half16<T>::to_f(df1[j]) * Half16<T>::to_f(of1[j]);
     d = quad_sum(d);
+    if (q >= S) {  // clamped duplicates of row S-1: no contribution
+      d = 0.f;
+      qf0 = qf1 = df0 = df1 = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     if (g == 0) del_s[q] = d;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PDT_STAMP(1);
   __syncthreads();
+  PDT_STAMP(2);
 
-  // sum over the 16 rows a wave holds (lane&15), result valid in lanes with (lane&15)==0
-  auto rows16 = [](float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-  };
-
-  // ---- dQ for query rows r0..r0+15
+  // ---- dQ for query rows r0..r0+15 (keys on the sweep axis)
   if (r0 < S) {
     const int q = r0 + lm;
-    const short8 qf0 = row_frag(qimg, r0, 0, lane), qf1 = row_frag(qimg, r0, 1, lane);
-    const short8 df0 = row_frag(dimg, r0, 0, lane), df1 = row_frag(dimg, r0, 1, lane);
-    const float lse = lse_s[q], delta = del_s[q];
+    // exp2(score2 + mask - lse2q) = p * scale: the softmax scale of dS is folded into the exponent
+    const float lse2q = lse_s[q] - __log2f(a.scale), ndelta = -del_s[q];
     const uint32_t rseed = seed_s[q], kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
     float4v dq[4];
 #pragma unroll
@@ -452,22 +524,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
         for (int hb = 0; hb < 2; ++hb) {
           const int kb16 = pb * 32 + hb * 16;
           float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sc = Half16<T>::mfma(row_frag(kimg, kb16, 0, lane), qf0, sc);
-          sc = Half16<T>::mfma(row_frag(kimg, kb16, 1, lane), qf1, sc);
-          dp = Half16<T>::mfma(row_frag(vimg, kb16, 0, lane), df0, dp);
-          dp = Half16<T>::mfma(row_frag(vimg, kb16, 1, lane), df1, dp);
+          sc = Half16<T>::mfma(row_frag(img0, kb16, 0, lane), qf0, sc);
+          sc = Half16<T>::mfma(row_frag(img0, kb16, 1, lane), qf1, sc);
+          dp = Half16<T>::mfma(row_frag(img1, kb16, 0, lane), df0, dp);
+          dp = Half16<T>::mfma(row_frag(img1, kb16, 1, lane), df1, dp);
           const float4v mb = *reinterpret_cast<const float4v*>(mbias + kb16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sc[r] * a.scale + mb[r] - lse);
-            float d = dp[r];
-            if (a.drop_thr != 0) d = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? d * a.drop_scale : 0.f;
-            ds[hb][r] = q < S ? p * (d - delta) * a.scale : 0.f;
+            const float ps = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb[r] - lse2q));
+            float e = dp[r] + ndelta;
+            if (drop)
+              e = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? fmaf(dp[r], a.drop_scale, ndelta) : ndelta;
+            ds[hb][r] = ps * e;
           }
         }
         const short8 dsf = pack_pair<T>(ds[0], ds[1]);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(kimg, pb * 32, db, lane), dsf, dq[db]);
+        for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(img0, pb * 32, db, lane), dsf, dq[db]);
       }
     }
     if (q < S) {
@@ -480,97 +553,114 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_fused128_kernel(AttnArgs
         *reinterpret_cast<short4v*>(out + db * 16 + 4 * g) = pk;
       }
     }
-    if (dbias) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = rows16(dq[db][r]);
-          if (lm == 0) atomicAdd(cs + db * 16 + 4 * g + r, v);
-        }
-    }
-  }
-
-  // ---- dK, dV for keys r0..r0+15 (keys at or beyond kv_len receive exactly zero gradient)
-  {
-    const int key = r0 + lm;
-    float4v dk_[4], dv_[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
-    if (r0 < kvl) {
-      const short8 kf0 = row_frag(kimg, r0, 0, lane), kf1 = row_frag(kimg, r0, 1, lane);
-      const short8 vf0 = row_frag(vimg, r0, 0, lane), vf1 = row_frag(vimg, r0, 1, lane);
-      const float mb = mbias[key];
-      const uint32_t kmul = (uint32_t)key * ATT_GOLD;
-#pragma unroll
-      for (int qb = 0; qb < NPB; ++qb) {
-        if (qb < nqb) {
-          float4v pp[2], ds[2];
-#pragma unroll
-          for (int hb = 0; hb < 2; ++hb) {
-            const int q16 = qb * 32 + hb * 16;
-            float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sc = Half16<T>::mfma(row_frag(qimg, q16, 0, lane), kf0, sc);
-            sc = Half16<T>::mfma(row_frag(qimg, q16, 1, lane), kf1, sc);
-            dp = Half16<T>::mfma(row_frag(dimg, q16, 0, lane), vf0, dp);
-            dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
-            const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
-            const float4v de = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g);
-            const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int q = q16 + 4 * g + r;
-              float p = __expf(sc[r] * a.scale + mb - ls[r]);
-              if (q >= S) p = 0.f;
-              float d = dp[r], pd = p;
-              if (a.drop_thr != 0) {
-                const bool keep = attn_keep(sd[r], kmul, thr_hi);
-                d = keep ? d * a.drop_scale : 0.f;
-                pd = keep ? p * a.drop_scale : 0.f;
-              }
-              pp[hb][r] = pd;
-              ds[hb][r] = p * (d - de[r]) * a.scale;
-            }
-          }
-          const short8 pf = pack_pair<T>(pp[0], pp[1]);
-          const short8 dsf = pack_pair<T>(ds[0], ds[1]);
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            dv_[db] = Half16<T>::mfma(tr_frag(dimg, qb * 32, db, lane), pf, dv_[db]);
-            dk_[db] = Half16<T>::mfma(tr_frag(qimg, qb * 32, db, lane), dsf, dk_[db]);
-          }
-        }
-      }
-    }
-    if (key < S) {
-      T* outk = (T*)a.dqkv + ((size_t)b * S + key) * ld + a.H + h * HD;
-      T* outv = outk + a.H;
+    if (dbias) {  // rows >= S are exactly zero (zero Q / dO fragments, p = 0)
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        short4v pk, pv;
+        float4v t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pk[r] = Half16<T>::from_f(dk_[db][r]); pv[r] = Half16<T>::from_f(dv_[db][r]); }
-        *reinterpret_cast<short4v*>(outk + db * 16 + 4 * g) = pk;
-        *reinterpret_cast<short4v*>(outv + db * 16 + 4 * g) = pv;
+        for (int r = 0; r < 4; ++r) t[r] = row16_sum(dq[db][r]);
+        if (lm == 0) *reinterpret_cast<float4v*>(csq + wave * 64 + db * 16 + 4 * g) = t;
       }
     }
-    if (dbias && r0 < kvl) {
+  } else if (dbias) {
+    csq[wave * 64 + lane] = 0.f;
+  }
+  PDT_STAMP(3);
+
+  // ---- dK, dV for keys r0..r0+15 (queries on the sweep axis); keys at or beyond kv_len get exactly zero
+  const int key = r0 + lm;
+  const bool kv_active = r0 < kvl;
+  short8 kf0, kf1, vf0, vf1;  // the wave's own keys
+  if (kv_active) {
+    kf0 = row_frag(img0, r0, 0, lane); kf1 = row_frag(img0, r0, 1, lane);
+    vf0 = row_frag(img1, r0, 0, lane); vf1 = row_frag(img1, r0, 1, lane);
+  }
+  const float mbk = mbias[key];
+  PDT_STAMP(4);
+  float4v dk_[4], dv_[4];
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
+  if (kv_active) {
+    const uint32_t kmul = (uint32_t)key * ATT_GOLD;
+    const float dsc2 = a.drop_scale * a.scale;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float vk = rows16(key < S ? dk_[db][r] : 0.f), vv = rows16(key < S ? dv_[db][r] : 0.f);
-          if (lm == 0) {
-            atomicAdd(cs + 64 + db * 16 + 4 * g + r, vk);
-            atomicAdd(cs + 128 + db * 16 + 4 * g + r, vv);
+    for (int qb = 0; qb < NPB; ++qb) {
+      if (qb < nqb) {
+        float4v pp[2], ds[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const int q16 = qb * 32 + hb * 16;
+          float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = Half16<T>::mfma(row_frag(img2, q16, 0, lane), kf0, sc);
+          sc = Half16<T>::mfma(row_frag(img2, q16, 1, lane), kf1, sc);
+          dp = Half16<T>::mfma(row_frag(img3, q16, 0, lane), vf0, dp);
+          dp = Half16<T>::mfma(row_frag(img3, q16, 1, lane), vf1, dp);
+          const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
+          const float4v nde = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g) * (-a.scale);
+          const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mbk - ls[r]));
+            float pd = p, e = fmaf(dp[r], a.scale, nde[r]);
+            if (drop) {
+              const bool keep = attn_keep(sd[r], kmul, thr_hi);
+              pd = keep ? p * a.drop_scale : 0.f;
+              e = keep ? fmaf(dp[r], dsc2, nde[r]) : nde[r];
+            }
+            pp[hb][r] = pd;
+            ds[hb][r] = p * e;
           }
         }
+        const short8 pf = pack_pair<T>(pp[0], pp[1]);
+        const short8 dsf = pack_pair<T>(ds[0], ds[1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv_[db] = Half16<T>::mfma(tr_frag(img3, qb * 32, db, lane), pf, dv_[db]);
+          dk_[db] = Half16<T>::mfma(tr_frag(img2, qb * 32, db, lane), dsf, dk_[db]);
+        }
+      }
     }
   }
-  if (dbias) {
-    __syncthreads();
-    if (tid < 192) atomicAdd(dbias + (tid >> 6) * a.H + h * HD + (tid & 63), cs[tid]);
+  if (key < S) {
+    T* outk = (T*)a.dqkv + ((size_t)b * S + key) * ld + a.H + h * HD;
+    T* outv = outk + a.H;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      short4v pk, pv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pk[r] = Half16<T>::from_f(dk_[db][r]); pv[r] = Half16<T>::from_f(dv_[db][r]); }
+      *reinterpret_cast<short4v*>(outk + db * 16 + 4 * g) = pk;
+      *reinterpret_cast<short4v*>(outv + db * 16 + 4 * g) = pv;
+    }
   }
+  PDT_STAMP(5);
+  if (dbias) {
+    // rows of keys >= S or >= kv_len are exactly zero in dk_/dv_
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      float4v tk, tv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { tk[r] = row16_sum(dk_[db][r]); tv[r] = row16_sum(dv_[db][r]); }
+      if (lm == 0) {
+        *reinterpret_cast<float4v*>(cskv + wave * 128 + db * 16 + 4 * g) = tk;
+        *reinterpret_cast<float4v*>(cskv + wave * 128 + 64 + db * 16 + 4 * g) = tv;
+      }
+    }
+    __syncthreads();
+    if (tid < 192) {
+      float t = 0.f;
+      if (tid < 64) {
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) t += csq[w * 64 + tid];
+      } else {
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) t += cskv[w * 128 + tid - 64];
+      }
+      dbias[(size_t)b * 3 * a.H + (tid >> 6) * a.H + h * HD + (tid & 63)] = t;
+    }
+  }
+  PDT_STAMP(6);
+#undef PDT_STAMP
 }
 
 template <typename KernT>
@@ -614,7 +704,7 @@ extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, con
 
 template <typename T>
 static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) {
-  const size_t lds = (size_t)4 * 128 * 128 + (size_t)(4 * 128 + 192) * sizeof(float);
+  const size_t lds = (size_t)4 * 128 * 128 + (size_t)(4 * 128 + ATT_WAVES * 192) * sizeof(float);
   auto kern = attn_bwd_fused128_kernel<T>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;

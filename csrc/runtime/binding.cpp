@@ -230,15 +230,19 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // attention core
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
-  // the short-sequence backward kernel also reduces the QKV bias gradient (atomic adds into gr[1])
+  // the short-sequence backward kernel also emits per-sample column sums of dqkv (the QKV bias gradient)
   const bool fused_db = pdt_attn_bwd_fuses_dbias((int)S) != 0;
-  if (fused_db && !accumulate) gr[1].zero_();
+  Tensor db_part = fused_db ? at::empty({B, 3 * (int64_t)H}, lse.options()) : Tensor();
   check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
                      dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
-                     fused_db ? gr[1].data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
+                     fused_db ? db_part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
                      thr16(p_attn), make_rng(rng_state, micro, site + 0), cur_stream()),
         "attn_bwd");
-  if (!fused_db) colsum_into(dqkv, gr[1], accumulate);
+  if (fused_db)
+    check(pdt_colsum_finish(db_part.data_ptr<float>(), (int)B, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, nullptr,
+                            accumulate ? 1 : 0, cur_stream()), "colsum_finish");
+  else
+    colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
   Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
   Tensor dx = gemm_nn(dqkv, w[0], e_add2);
@@ -472,10 +476,17 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
   Tensor dc = dctx.contiguous();
   PdtRng rng{nullptr, 0, 0};
   if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  // `dbias` (fp32 [3H]): the column sums of dqkv are added to it (short-sequence kernel only)
+  const int64_t H3 = qkv.size(1);
+  Tensor part;
+  if (dbias.has_value()) { chkf32(*dbias, "dbias"); part = at::empty({B, H3}, lse.options()); }
   check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
                      dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
-                     dbias.has_value() ? dbias->data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p),
+                     dbias.has_value() ? part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p),
                      thr16(p), rng, cur_stream()), "attn_bwd");
+  if (dbias.has_value())
+    check(pdt_colsum_finish(part.data_ptr<float>(), (int)B, (int)H3, 1, dbias->data_ptr<float>(), nullptr, nullptr, nullptr, 1,
+                            cur_stream()), "colsum_finish");
   return dqkv;
 }
 

@@ -270,6 +270,23 @@ def test_attention_general_mask_and_dropout(dtype):
     assert ctx0.shape == ctx.shape
 
 
+@pytest.mark.parametrize("S", [128, 160])
+def test_attention_fully_masked_sample_is_finite(S):
+    """A sample whose keys are all masked gets zero context and zero gradients (no NaN from exp(-inf + inf))."""
+    torch.manual_seed(8)
+    B, A = 2, 2
+    H = A * 64
+    qkv = torch.randn(B * S, 3 * H, device="cuda").half()
+    mask = torch.ones(B, S, dtype=torch.int32, device="cuda")
+    mask[1] = 0
+    kv_len = torch.tensor([S, S], dtype=torch.int32, device="cuda")
+    ctx, lse = C().op_attn_fwd(qkv, mask, kv_len, B, S, A, None, 0.0, 0, 0)
+    assert torch.isfinite(ctx.float()).all() and ctx.view(B, S, H)[1].abs().max().item() == 0
+    dctx = torch.randn(B * S, H, device="cuda").half()
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, None, 0.0, 0, 0)
+    assert torch.isfinite(dqkv.float()).all() and dqkv.view(B, S, 3 * H)[1].abs().max().item() == 0
+
+
 # ------------------------------------------------------------------------------------------ embeddings / head / optimizer
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_embeddings_fwd_bwd(dtype):
