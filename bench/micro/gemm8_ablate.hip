@@ -1,12 +1,17 @@
 // Standalone ablation harness for the ping-pong GEMM: builds the kernel with parts of a phase compiled out
 // (PDT_ABLATE: 0 = full kernel, 1 = no LDS-DMA in the K loop, 2 = no LDS fragment reads, 3 = no MFMA) and times
 // it on one BERT-large shape with random data.  Outputs of ablated builds are wrong by construction.
+// -DPDT_LAYOUT=0 (default) NT: A[M,K] B[N,K];  1 NN: A[M,K] B[K,N];  2 TN: A[K,M] B[K,N] with split-K fp32 slabs
+// (as many K slices as fill 256 workgroups).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "../../csrc/kernels/gemm8.hpp"
 
+#ifndef PDT_LAYOUT
+#define PDT_LAYOUT 0
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -16,16 +21,22 @@ int main(int argc, char** argv) {
   for (auto& v : ha) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
   for (auto& v : hb) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
   _Float16 *A, *B, *C;
-  CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+  constexpr bool AKS = PDT_LAYOUT == 2, BKS = PDT_LAYOUT >= 1;
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int splits = 1;
+  if (PDT_LAYOUT == 2) { splits = 256 / tiles; if (splits < 1) splits = 1; }
+  CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4 * splits));
   CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
   PdtGemm g{};
-  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.epi = PDT_EPI_PLAIN;
-  g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256; g.splits = 1; g.k_per_split = K;
-  auto kern = pdt::gemm8_kernel<_Float16, false, false>;
-  using KK = pdt::Gemm8<_Float16, false, false>;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = AKS ? M : K; g.ldb = BKS ? N : K; g.ldc = N;
+  g.epi = PDT_LAYOUT == 2 ? PDT_EPI_SLAB_F32 : PDT_EPI_PLAIN;
+  g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256; g.splits = splits;
+  g.k_per_split = ((K / 64 + splits - 1) / splits) * 64;
+  auto kern = pdt::gemm8_kernel<_Float16, AKS, BKS>;
+  using KK = pdt::Gemm8<_Float16, AKS, BKS>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KK::LDS_BYTES));
-  const int grid = g.tiles_m * g.tiles_n;
+  const int grid = g.tiles_m * g.tiles_n * splits;
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
@@ -37,6 +48,6 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
     if (ms / 10 < best) best = ms / 10;
   }
-  printf("ablate=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_ABLATE, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
+  printf("layout=%d phases=%d ablate=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
   return 0;
 }

@@ -34,16 +34,16 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
   if (a_bytes >= 0x7FFF0000ll || b_bytes >= 0x7FFF0000ll) return -4;
   if (tile < 0) {
     // measured on MI355X (bench/gemm_bench.py, BERT-large shapes): the ping-pong 256x256 kernel wins for
-    // forward / dgrad once its tiles fill most of the 256 CUs; weight gradients (both operands read with
-    // transposed LDS reads) run faster on the single-barrier 256x256 kernel; small problems use 128x128
+    // forward / dgrad once its tiles fill most of the 256 CUs, and for weight gradients (split-K fills the
+    // CUs whatever the tile count) as soon as the output holds one 256x256 tile; small problems use 128x128
     // tiles at two workgroups per CU
     const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-    if (layout == PDT_GEMM_TN) tile = (g->M >= 256 && g->N >= 256) ? 1 : 0;
+    if (layout == PDT_GEMM_TN) tile = (g->M >= 256 && g->N >= 256) ? 2 : 0;
     else tile = t256 >= 128 ? 2 : 0;
   }
   if (layout == PDT_GEMM_TN) {
     if (g->epi != PDT_EPI_SLAB_F32) return -5;
-    const int bt = tile == 1 ? 256 : 128;
+    const int bt = tile == 0 ? 128 : 256;
     const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
     const int ktiles = (g->K + 63) / 64;
     if (g->splits <= 0) {

@@ -5,7 +5,7 @@
 namespace pdt {
 
 constexpr int LN_MAX_CHUNKS = 4;   // 8-element chunks per lane  => H <= 2048
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 768;
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
