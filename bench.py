@@ -5,7 +5,9 @@ The configuration is the reference's data-parallel launch (bert-large-cased, MRP
 16-bit mixed precision, AdamW lr 2e-5 with linear warm-up, dropout 0.1;
 /root/reference/test_data_parallelism.py:69-150,174) on synthetic token batches of seq 128 with random-init
 weights.  Every timed step is a full optimizer step: forward, backward (with the bucketed gradient
-all-reduce when N > 1), fused AdamW with dynamic loss scaling, LR schedule, zero_grad.
+all-reduce when N > 1), fused AdamW with dynamic loss scaling, LR schedule, zero_grad.  The per-GPU batch
+defaults to 256 samples in one micro-batch (weak scaling: it stays fixed as N grows); the reference's literal
+"96 = 12 x 8" accumulation layout is `--batch 96 --accum 12`.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -37,7 +39,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="bert-large-cased")
     ap.add_argument("--seq-len", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU samples per optimizer step")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="per-GPU samples per optimizer step (sized for 288 GB HBM, not for the reference's 8-sample micro-batches)")
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])

@@ -36,7 +36,8 @@ int main(int argc, char** argv) {
   auto kern = pdt::gemm8_kernel<_Float16, AKS, BKS>;
   using KK = pdt::Gemm8<_Float16, AKS, BKS>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KK::LDS_BYTES));
-  const int grid = g.tiles_m * g.tiles_n * splits;
+  const int total = g.tiles_m * g.tiles_n * splits;
+  const int grid = total;
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
