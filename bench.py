@@ -94,7 +94,7 @@ def main() -> None:
     value = global_batch * args.steps / dt
     if eng.is_main_process:
         print(json.dumps({
-            "metric": "training samples/sec (node) BERT-large seq128",
+            "metric": f"training samples/sec (node) {_pretty(args.model)} seq{args.seq_len}",
             "value": round(value, 2),
             "unit": "samples/s",
             "n_gpus": world,
@@ -116,6 +116,11 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pretty(model: str) -> str:
+    return {"bert-large-cased": "BERT-large", "bert-base-cased": "BERT-base", "roberta-large": "RoBERTa-large",
+            "roberta-base": "RoBERTa-base"}.get(model, model)
 
 
 class _null:

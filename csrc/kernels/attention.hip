@@ -1,6 +1,6 @@
 // Fused scaled-dot-product attention for BERT-class encoders on gfx950: head_dim 64, S <= 512, key padding
-// mask, dropout on the probabilities.  Forward keeps the whole key/value panel of one (batch, head) in LDS
-// (S=512: 2 x 64 KiB) and a full score row in registers, so there is no online-softmax rescale.
+// mask, dropout on the probabilities.  Forward streams the keys through LDS in 128-row chunks with an online
+// softmax (one chunk = the whole sequence at S <= 128, where the rescale is a no-op).
 // Backward recomputes the probabilities from the saved log-sum-exp in two sweeps with no atomics on dQ/dK/dV:
 //   dQ sweep    : one wave = 16 query rows, sweeps the keys       (S^T, dP^T -> dS^T -> dQ^T)
 //   dK/dV sweep : one wave = 16 keys,       sweeps the queries    (S, dP -> P, dS -> dV^T, dK^T)
@@ -57,41 +57,19 @@ __device__ __forceinline__ bool attn_keep(uint32_t row_seed, uint32_t kmul, uint
 }
 __device__ __forceinline__ uint32_t attn_thr_hi(uint32_t thr) { return (thr > 65535u ? 65535u : thr) << 16; }
 
-// cooperative load of `nrows_pad` rows of 64 16-bit values (row stride `stride` elements) into an image
+// LDS-DMA fill of one 128-row image of 64 16-bit values per row (2 x 1 KiB pieces per wave) from rows
+// [0, 128) of `src` (row stride `stride` elements): the swizzle (16-B chunk ^= row & 6) is applied on the per-lane
+// SOURCE address because a DMA write is lane-linear; rows at or beyond `nvalid` read out of bounds and arrive as
+// zeros.  Completion: s_waitcnt vmcnt(0) + barrier by the caller.
 template <typename T>
-__device__ __forceinline__ void load_image(char* img, const T* src, int stride, int nvalid, int nrows_pad, int tid) {
-  for (int idx = tid; idx < nrows_pad * 8; idx += ATT_THREADS) {
-    const int row = idx >> 3, c = idx & 7;
-    short8 v = short8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < nvalid) v = *reinterpret_cast<const short8*>(src + (size_t)row * stride + c * 8);
-    *reinterpret_cast<short8*>(img + row * 128 + ((c ^ (row & 6)) << 4)) = v;
-  }
-}
-// The same for NIMG images at once: all global loads of a pass (2 chunks per image and thread) are in flight
-// before the first LDS write, so a workgroup pays one memory latency per pass instead of one per chunk.
-template <typename T, int NIMG>
-__device__ __forceinline__ void load_images(char* const (&img)[NIMG], const T* const (&src)[NIMG], const int (&stride)[NIMG],
-                                            const int (&nvalid)[NIMG], const int (&nrows_pad)[NIMG], int tid) {
-  int maxpad = 0;
+__device__ __forceinline__ void dma_image128(char* img, const T* src, int stride, int nvalid, int tid, int wave) {
+  const uint32_t bytes = nvalid > 0 ? (uint32_t)(((size_t)(nvalid - 1) * stride + HD) * 2) : 0u;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, bytes, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < NIMG; ++i) maxpad = max(maxpad, nrows_pad[i]);
-  for (int base = 0; base < maxpad * 8; base += 2 * ATT_THREADS) {
-    short8 v[NIMG][2];
-#pragma unroll
-    for (int i = 0; i < NIMG; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = base + u * ATT_THREADS + tid, row = idx >> 3, c = idx & 7;
-        v[i][u] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < nvalid[i] && row < nrows_pad[i]) v[i][u] = *reinterpret_cast<const short8*>(src[i] + (size_t)row * stride[i] + c * 8);
-      }
-#pragma unroll
-    for (int i = 0; i < NIMG; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int idx = base + u * ATT_THREADS + tid, row = idx >> 3, c = idx & 7;
-        if (row < nrows_pad[i]) *reinterpret_cast<short8*>(img[i] + row * 128 + ((c ^ (row & 6)) << 4)) = v[i][u];
-      }
+  for (int u = 0; u < 2; ++u) {
+    const int idx = u * ATT_THREADS + tid, row = idx >> 3, c = (idx & 7) ^ (row & 6);
+    const uint32_t off = row < nvalid ? ((uint32_t)row * stride + c * 8) * 2u : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(img + (u * ATT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
   }
 }
 // rows x0..x0+15 as an MFMA A operand: lane -> row x0+(lane&15), k = 8*(lane>>4)+j of k-step ks (k = head dim)
@@ -136,163 +114,196 @@ __device__ __forceinline__ float quad_max(float v) {
   return v;
 }
 
+// All three kernels below walk the key (or query) axis in chunks of 128 rows: two 16-KiB LDS images are re-filled
+// per chunk, so the footprint is ~34-38 KiB for any S <= 512 and four workgroups (32 waves) share a CU - these
+// kernels are VALU-bound (exp, dropout hash, scaling per score element against 4 MFMAs per 16x16 block at
+// head dim 64), so what they need is waves to interleave, not a resident K/V panel.
+constexpr int ATT_SMAX = 512;   // longest sequence
+constexpr int ATT_CHUNK = 128;  // rows per LDS image
+
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int SMAX>
+// One wave = 16 query rows.  Online softmax over the key chunks in the log2 domain: running maximum m, running
+// sum l (per lane, reduced once at the end), output accumulators rescaled by exp2(m_old - m_new) per chunk.
+// Dropout multiplies the un-normalised probabilities (the 1/l factor is applied to the output at the end).
+template <typename T>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
-  constexpr int NPB = SMAX / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
-  char* vimg = smem + SMAX * 128;
-  float* mbias = reinterpret_cast<float*>(smem + 2 * SMAX * 128);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* vimg = smem + ATT_CHUNK * 128;
+  float* mbias = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
   const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
   const int kvl = min(a.kv_len[b], S);
   const int npb = (kvl + 31) >> 5;
-  load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
-  load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
   for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
-  __syncthreads();
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
-  if (q0 >= S) return;
+  const bool active = q0 < S;  // wave-uniform
   const int lm = lane & 15, g = lane >> 4;
   const int q = q0 + lm, qc = min(q, S - 1);
   const short8 qf0 = gfrag<T>(base, qc, ld, 0, lane), qf1 = gfrag<T>(base, qc, ld, 1, lane);
-
-  float4v s[2 * NPB];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kb = 0; kb < 2 * NPB; ++kb) {
-    if (kb < 2 * npb) {
-      float4v acc = {0.f, 0.f, 0.f, 0.f};
-      acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 0, lane), qf0, acc);
-      acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 1, lane), qf1, acc);
-      const float4v mb = *reinterpret_cast<const float4v*>(mbias + kb * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { acc[r] = acc[r] * a.scale + mb[r]; mx = fmaxf(mx, acc[r]); }
-      s[kb] = acc;
-    }
-  }
-  mx = quad_max(mx);
-  if (mx == -INFINITY) mx = 0.f;
-  float l = 0.f;
-#pragma unroll
-  for (int kb = 0; kb < 2 * NPB; ++kb) {
-    if (kb < 2 * npb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s[kb][r] = __expf(s[kb][r] - mx); l += s[kb][r]; }
-    }
-  }
-  l = quad_sum(l);
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  // a row whose keys are all masked has no probability mass: lse = +inf makes every recomputed p exactly 0
-  if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = l > 0.f ? mx + __logf(l) : INFINITY;
-
+  const float k2 = a.scale * LOG2E;
   const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
+  const bool drop = a.drop_thr != 0;
+
+  float m = -INFINITY, l = 0.f;
   float4v o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < npb * 32; c0 += ATT_CHUNK) {
+    if (c0) __syncthreads();  // every wave is done with the previous chunk
+    dma_image128<T>(kimg, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    dma_image128<T>(vimg, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) continue;
+    const int nb = min(ATT_CHUNK / 32, npb - (c0 >> 5));  // 32-key blocks in this chunk
+    float4v s[8];
+    float cmax = -INFINITY;
 #pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    if (pb < npb) {
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb < 2 * nb) {
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 0, lane), qf0, acc);
+        acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 1, lane), qf1, acc);
+        const float4v mb = *reinterpret_cast<const float4v*>(mbias + c0 + kb * 16 + 4 * g);
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = s[2 * pb + hb][r] * inv;
-          if (a.drop_thr != 0)
-            p = attn_keep(rseed, kmul0 + (uint32_t)(pb * 32 + hb * 16 + r) * ATT_GOLD, thr_hi) ? p * a.drop_scale : 0.f;
-          s[2 * pb + hb][r] = p;
-        }
+        for (int r = 0; r < 4; ++r) { acc[r] = fmaf(acc[r], k2, mb[r]); cmax = fmaxf(cmax, acc[r]); }
+        s[kb] = acc;
       }
-      const short8 pf = pack_pair<T>(s[2 * pb], s[2 * pb + 1]);
+    }
+    cmax = quad_max(cmax);
+    const float m_new = fmaxf(m, cmax);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;  // all keys so far masked: exp2(-inf - 0) = 0
+    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+    m = m_new;
+    l *= alpha;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) o[db] = Half16<T>::mfma(tr_frag(vimg, pb * 32, db, lane), pf, o[db]);
+    for (int db = 0; db < 4; ++db) o[db] *= alpha;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      if (pb < nb) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[2 * pb + hb][r] - m_use);
+            l += p;
+            if (drop)
+              p = attn_keep(rseed, kmul0 + (uint32_t)(c0 + pb * 32 + hb * 16 + r) * ATT_GOLD, thr_hi) ? p * a.drop_scale : 0.f;
+            s[2 * pb + hb][r] = p;
+          }
+        }
+        const short8 pf = pack_pair<T>(s[2 * pb], s[2 * pb + 1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = Half16<T>::mfma(tr_frag(vimg, pb * 32, db, lane), pf, o[db]);
+      }
     }
   }
+  if (!active) return;
+  l = quad_sum(l);
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+  // a row whose keys are all masked has no probability mass: lse = +inf makes every recomputed p exactly 0
+  if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = l > 0.f ? (m + __log2f(l)) * (1.0f / LOG2E) : INFINITY;
   if (q < S) {
     T* out = (T*)a.ctx + ((size_t)b * S + q) * a.H + h * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       short4v pk;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pk[r] = Half16<T>::from_f(o[db][r]);
+      for (int r = 0; r < 4; ++r) pk[r] = Half16<T>::from_f(o[db][r] * inv);
       *reinterpret_cast<short4v*>(out + db * 16 + 4 * g) = pk;
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------------ dQ
-template <typename T, int SMAX>
+// ------------------------------------------------------------------------------------------------ dQ (S > 128)
+// One wave = 16 query rows, sweeps the keys chunk by chunk; also produces delta = rowsum(dO * O) for the
+// dK/dV kernel.  Log2-domain recomputation with the softmax scale folded into the exponent.
+template <typename T>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
-  constexpr int NPB = SMAX / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
-  char* vimg = smem + SMAX * 128;
-  float* mbias = reinterpret_cast<float*>(smem + 2 * SMAX * 128);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* vimg = smem + ATT_CHUNK * 128;
+  float* mbias = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
   const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
+  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
+  const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
   const int kvl = min(a.kv_len[b], S);
   const int npb = (kvl + 31) >> 5;
-  load_image<T>(kimg, base + a.H, ld, S, npb * 32, tid);
-  load_image<T>(vimg, base + 2 * a.H, ld, S, npb * 32, tid);
   for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
-  __syncthreads();
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
-  if (q0 >= S) return;
+  const bool active = q0 < S;  // wave-uniform
   const int lm = lane & 15, g = lane >> 4;
   const int q = q0 + lm, qc = min(q, S - 1);
   const short8 qf0 = gfrag<T>(base, qc, ld, 0, lane), qf1 = gfrag<T>(base, qc, ld, 1, lane);
-  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
-  const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
   const short8 df0 = gfrag<T>(dob, qc, a.H, 0, lane), df1 = gfrag<T>(dob, qc, a.H, 1, lane);
-  float delta;
+  float ndelta;
   {
     const short8 of0 = gfrag<T>(ob, qc, a.H, 0, lane), of1 = gfrag<T>(ob, qc, a.H, 1, lane);
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       d += Half16<T>::to_f(df0[j]) * Half16<T>::to_f(of0[j]) + Half16<T>::to_f(df1[j]) * Half16<T>::to_f(of1[j]);
-    delta = quad_sum(d);
-    if (g == 0 && q < S) a.delta[(size_t)bh * S + q] = delta;
+    d = quad_sum(d);
+    if (active && g == 0 && q < S) a.delta[(size_t)bh * S + q] = d;
+    ndelta = -d;
   }
-  const float lse = a.lse[(size_t)bh * S + qc];
+  const float k2 = a.scale * LOG2E;
+  // exp2(score2 + mask - lse2q) = p * scale; rows >= S get lse = +inf, i.e. p = 0 and a zero dQ row
+  const float lse2q = (q < S ? a.lse[(size_t)bh * S + qc] * LOG2E : INFINITY) - __log2f(a.scale);
   const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
+  const bool drop = a.drop_thr != 0;
   float4v dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int pb = 0; pb < npb; ++pb) {
-    float4v ds[2];
+  for (int c0 = 0; c0 < npb * 32; c0 += ATT_CHUNK) {
+    if (c0) __syncthreads();
+    dma_image128<T>(kimg, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    dma_image128<T>(vimg, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) continue;
+    const int nb = min(ATT_CHUNK / 32, npb - (c0 >> 5));
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int kb16 = pb * 32 + hb * 16;
-      float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      sc = Half16<T>::mfma(row_frag(kimg, kb16, 0, lane), qf0, sc);
-      sc = Half16<T>::mfma(row_frag(kimg, kb16, 1, lane), qf1, sc);
-      dp = Half16<T>::mfma(row_frag(vimg, kb16, 0, lane), df0, dp);
-      dp = Half16<T>::mfma(row_frag(vimg, kb16, 1, lane), df1, dp);
-      const float4v mb = *reinterpret_cast<const float4v*>(mbias + kb16 + 4 * g);
+    for (int pb = 0; pb < 4; ++pb) {
+      if (pb < nb) {
+        float4v ds[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(sc[r] * a.scale + mb[r] - lse);
-        float d = dp[r];
-        if (a.drop_thr != 0) d = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? d * a.drop_scale : 0.f;
-        ds[hb][r] = p * (d - delta) * a.scale;
+        for (int hb = 0; hb < 2; ++hb) {
+          const int kb16 = pb * 32 + hb * 16;
+          float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sc = Half16<T>::mfma(row_frag(kimg, kb16, 0, lane), qf0, sc);
+          sc = Half16<T>::mfma(row_frag(kimg, kb16, 1, lane), qf1, sc);
+          dp = Half16<T>::mfma(row_frag(vimg, kb16, 0, lane), df0, dp);
+          dp = Half16<T>::mfma(row_frag(vimg, kb16, 1, lane), df1, dp);
+          const float4v mb = *reinterpret_cast<const float4v*>(mbias + c0 + kb16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ps = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb[r] - lse2q));
+            float e = dp[r] + ndelta;
+            if (drop)
+              e = attn_keep(rseed, kmul0 + (uint32_t)(c0 + kb16 + r) * ATT_GOLD, thr_hi) ? fmaf(dp[r], a.drop_scale, ndelta) : ndelta;
+            ds[hb][r] = ps * e;
+          }
+        }
+        const short8 dsf = pack_pair<T>(ds[0], ds[1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(kimg, pb * 32, db, lane), dsf, dq[db]);
       }
     }
-    const short8 dsf = pack_pair<T>(ds[0], ds[1]);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(kimg, pb * 32, db, lane), dsf, dq[db]);
   }
-  if (q < S) {
+  if (active && q < S) {
     T* out = (T*)a.dqkv + ((size_t)b * S + q) * ld + h * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -304,16 +315,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, int SMAX>
+// ------------------------------------------------------------------------------------------------ dK, dV (S > 128)
+// One wave = 16 keys, sweeps the queries chunk by chunk (Q and dO images); per-row lse / delta / dropout seeds
+// of the whole sequence are staged in LDS once.
+template <typename T>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
-  char* dimg = smem + SMAX * 128;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * SMAX * 128);
-  float* del_s = lse_s + SMAX;
-  uint32_t* seed_s = reinterpret_cast<uint32_t*>(del_s + SMAX);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* dimg = smem + ATT_CHUNK * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  float* del_s = lse_s + ATT_SMAX;
+  uint32_t* seed_s = reinterpret_cast<uint32_t*>(del_s + ATT_SMAX);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
   const int S = a.S, ld = 3 * a.H;
   const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
@@ -322,64 +336,71 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   const DropKey dk = drop_key(a.rng);
   const int kvl = min(a.kv_len[b], S);
   const int k0 = blockIdx.y * ATT_ROWS + wave * 16;
-  // keys at or beyond kv_len receive exactly zero gradient: the block only has to write zeros
-  const bool active = blockIdx.y * ATT_ROWS < kvl;
-  if (active) {
-    load_image<T>(qimg, base, ld, S, nqb * 32, tid);
-    load_image<T>(dimg, dob, a.H, S, nqb * 32, tid);
-    for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
-      lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] : 0.f;
-      del_s[i] = i < S ? a.delta[(size_t)bh * S + i] : 0.f;
-      seed_s[i] = attn_row_seed(dk, bh, i);
-    }
-  }
-  __syncthreads();
-  if (k0 >= S) return;
+  // keys at or beyond kv_len receive exactly zero gradient: such a workgroup / wave only writes zeros
+  const bool blk_active = blockIdx.y * ATT_ROWS < kvl;  // workgroup-uniform
+  const bool wave_active = k0 < kvl;                    // wave-uniform
   const int lm = lane & 15, g = lane >> 4;
   const int key = k0 + lm, kc = min(key, S - 1);
   float4v dk_[4], dv_[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
-  if (active && k0 < kvl) {
+  if (blk_active) {
+    for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
+      // log2-domain lse, +inf for the padding rows (p = 0); delta pre-multiplied by -scale
+      lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] * LOG2E : INFINITY;
+      del_s[i] = i < S ? -a.scale * a.delta[(size_t)bh * S + i] : 0.f;
+      seed_s[i] = attn_row_seed(dk, bh, i);
+    }
     const short8 kf0 = gfrag<T>(base + a.H, kc, ld, 0, lane), kf1 = gfrag<T>(base + a.H, kc, ld, 1, lane);
     const short8 vf0 = gfrag<T>(base + 2 * a.H, kc, ld, 0, lane), vf1 = gfrag<T>(base + 2 * a.H, kc, ld, 1, lane);
     const float mb = (key < S && a.mask[(size_t)b * S + kc] != 0) ? 0.f : -INFINITY;
     const uint32_t kmul = (uint32_t)key * ATT_GOLD, thr_hi = attn_thr_hi(a.drop_thr);
-#pragma unroll 1
-    for (int qb = 0; qb < nqb; ++qb) {
-      float4v pp[2], ds[2];
+    const float k2 = a.scale * LOG2E, dsc2 = a.drop_scale * a.scale;
+    const bool drop = a.drop_thr != 0;
+    for (int c0 = 0; c0 < nqb * 32; c0 += ATT_CHUNK) {
+      if (c0) __syncthreads();
+      dma_image128<T>(qimg, base + (size_t)c0 * ld, ld, S - c0, tid, wave);
+      dma_image128<T>(dimg, dob + (size_t)c0 * a.H, a.H, S - c0, tid, wave);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // also orders the lse / delta / seed staging before its first use
+      if (!wave_active) continue;
+      const int nb = min(ATT_CHUNK / 32, nqb - (c0 >> 5));
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        const int q16 = qb * 32 + hb * 16;
-        float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sc = Half16<T>::mfma(row_frag(qimg, q16, 0, lane), kf0, sc);
-        sc = Half16<T>::mfma(row_frag(qimg, q16, 1, lane), kf1, sc);
-        dp = Half16<T>::mfma(row_frag(dimg, q16, 0, lane), vf0, dp);
-        dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
-        const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
-        const float4v de = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g);
-        const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
+      for (int qb = 0; qb < 4; ++qb) {
+        if (qb < nb) {
+          float4v pp[2], ds[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = q16 + 4 * g + r;
-          float p = __expf(sc[r] * a.scale + mb - ls[r]);
-          if (q >= S) p = 0.f;
-          float d = dp[r], pd = p;
-          if (a.drop_thr != 0) {
-            const bool keep = attn_keep(sd[r], kmul, thr_hi);
-            d = keep ? d * a.drop_scale : 0.f;
-            pd = keep ? p * a.drop_scale : 0.f;
+          for (int hb = 0; hb < 2; ++hb) {
+            const int q16 = qb * 32 + hb * 16;
+            float4v sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sc = Half16<T>::mfma(row_frag(qimg, q16, 0, lane), kf0, sc);
+            sc = Half16<T>::mfma(row_frag(qimg, q16, 1, lane), kf1, sc);
+            dp = Half16<T>::mfma(row_frag(dimg, q16, 0, lane), vf0, dp);
+            dp = Half16<T>::mfma(row_frag(dimg, q16, 1, lane), vf1, dp);
+            const float4v ls = *reinterpret_cast<const float4v*>(lse_s + c0 + q16 + 4 * g);
+            const float4v nde = *reinterpret_cast<const float4v*>(del_s + c0 + q16 + 4 * g);
+            const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + c0 + q16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb - ls[r]));
+              float pd = p, e = fmaf(dp[r], a.scale, nde[r]);
+              if (drop) {
+                const bool keep = attn_keep(sd[r], kmul, thr_hi);
+                pd = keep ? p * a.drop_scale : 0.f;
+                e = keep ? fmaf(dp[r], dsc2, nde[r]) : nde[r];
+              }
+              pp[hb][r] = pd;
+              ds[hb][r] = p * e;
+            }
           }
-          pp[hb][r] = pd;
-          ds[hb][r] = p * (d - de[r]) * a.scale;
-        }
-      }
-      const short8 pf = pack_pair<T>(pp[0], pp[1]);
-      const short8 dsf = pack_pair<T>(ds[0], ds[1]);
+          const short8 pf = pack_pair<T>(pp[0], pp[1]);
+          const short8 dsf = pack_pair<T>(ds[0], ds[1]);
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        dv_[db] = Half16<T>::mfma(tr_frag(dimg, qb * 32, db, lane), pf, dv_[db]);
-        dk_[db] = Half16<T>::mfma(tr_frag(qimg, qb * 32, db, lane), dsf, dk_[db]);
+          for (int db = 0; db < 4; ++db) {
+            dv_[db] = Half16<T>::mfma(tr_frag(dimg, qb * 32, db, lane), pf, dv_[db]);
+            dk_[db] = Half16<T>::mfma(tr_frag(qimg, qb * 32, db, lane), dsf, dk_[db]);
+          }
+        }
       }
     }
   }
@@ -416,20 +437,6 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x121>(v);  // row_ror:1
   return v;
 }
-// LDS-DMA fill of one 128-row image (2 x 1 KiB pieces per wave): the swizzle is applied on the per-lane SOURCE
-// address because a DMA write is lane-linear; rows in [nvalid, 128) read out of bounds and arrive as zeros.
-template <typename T>
-__device__ __forceinline__ void dma_image128(char* img, const T* src, int stride, int nvalid, int tid, int wave) {
-  const uint32_t bytes = (uint32_t)(((size_t)(nvalid - 1) * stride + HD) * 2);
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, bytes, 0x00020000);
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = u * ATT_THREADS + tid, row = idx >> 3, c = (idx & 7) ^ (row & 6);
-    const uint32_t off = row < nvalid ? ((uint32_t)row * stride + c * 8) * 2u : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(img + (u * ATT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
-  }
-}
-
 #ifndef PDT_ATT_FUSED_WAVES_EU  // minimum waves per SIMD the register allocation of the fused kernel must allow
 #define PDT_ATT_FUSED_WAVES_EU 4
 #endif
@@ -664,32 +671,25 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
 }
 
 template <typename KernT>
-static int launch_attn(KernT kern, const AttnArgs& a, int smax, hipStream_t stream) {
-  const size_t lds = (size_t)2 * smax * 128 + (size_t)3 * smax * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a);
   return (int)hipGetLastError();
 }
 
+// which: 0 forward, 1 dQ, 2 dK/dV
 template <typename T>
 static int attn_dispatch(int which, const AttnArgs& a, hipStream_t s) {
-#define PDT_CASE(SM)                                                              \
-  if (a.S <= SM) {                                                                \
-    if (which == 0) return launch_attn(attn_fwd_kernel<T, SM>, a, SM, s);         \
-    if (which == 1) return launch_attn(attn_bwd_dq_kernel<T, SM>, a, SM, s);      \
-    return launch_attn(attn_bwd_dkv_kernel<T, SM>, a, SM, s);                     \
-  }
-  PDT_CASE(128) PDT_CASE(256) PDT_CASE(384) PDT_CASE(512)
-#undef PDT_CASE
-  return -3;
+  const size_t imgs = (size_t)2 * ATT_CHUNK * 128;
+  if (which == 0) return launch_attn(attn_fwd_kernel<T>, a, imgs + ATT_SMAX * sizeof(float), s);
+  if (which == 1) return launch_attn(attn_bwd_dq_kernel<T>, a, imgs + ATT_SMAX * sizeof(float), s);
+  return launch_attn(attn_bwd_dkv_kernel<T>, a, imgs + 3 * ATT_SMAX * sizeof(float), s);
 }
 
 }  // namespace pdt
 
 using namespace pdt;
 
-static int check_attn(int B, int S, int A) { return (B <= 0 || S <= 0 || S > 512 || A <= 0) ? -3 : 0; }
+static int check_attn(int B, int S, int A) { return (B <= 0 || S <= 0 || S > ATT_SMAX || A <= 0) ? -3 : 0; }
 
 extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, void* ctx,
                             float* lse, int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng,
