@@ -4,8 +4,11 @@
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/HIPEvent.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "../kernels/api.h"
@@ -18,6 +21,63 @@ namespace {
 // PyTorch-ROCm names its device type "cuda"; these are the guard / stream classes that accept it.
 using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
 void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+
+// Weight-gradient lane: in the layer backward the wgrad GEMM of a projection does not feed anything later in the
+// layer, so it can be issued on a second HIP stream and run concurrently with the dgrad chain.  Measured on
+// MI355X (BERT-large, seq 128): +5 % step throughput at 8192 tokens per micro-batch and +1.6 % at 4096 (the
+// GEMMs of such a micro-batch leave CUs idle in their tail rounds, the concurrent kernel fills them), but
+// -1.3 % at 16384 and -3.4 % at 32768 tokens, where every GEMM fills the chip by itself and two of them only
+// compete for L2.  Mode 1 (default) therefore uses the lane up to 12288 tokens; PDT_WGRAD_STREAM=0 never, =2
+// always.  Fork = event on the main stream the side stream
+// waits for; join = event on the side stream the main stream waits for before the layer returns, which also
+// makes the caching allocator's stream-ordered reuse of this layer's temporaries safe.
+using Stream = c10::hip::HIPStreamMasqueradingAsCUDA;
+using StreamGuard = c10::hip::HIPStreamGuardMasqueradingAsCUDA;
+int g_wgrad_mode = [] {
+  const char* e = std::getenv("PDT_WGRAD_STREAM");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+}();
+constexpr int kWgradLaneMaxTokens = 12288;
+class WgradLane {
+ public:
+  explicit WgradLane(bool enabled) : on_(enabled), main_(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA()), side_(main_) {
+    if (on_) side_ = side_stream(main_.device_index());
+  }
+  // run `fn` (kernel launches + its temporaries) on the side stream, after everything issued so far on main
+  template <typename F>
+  void run(F&& fn) {
+    if (!on_) { fn(); return; }
+    event(next_++).record(main_);
+    event(next_ - 1).block(side_);
+    StreamGuard g(side_);
+    fn();
+    used_ = true;
+  }
+  void join() {
+    if (!on_ || !used_) return;
+    event(next_++).record(side_);
+    event(next_ - 1).block(main_);
+    used_ = false;
+  }
+  ~WgradLane() { join(); }
+
+ private:
+  static Stream side_stream(c10::DeviceIndex dev) {
+    static std::vector<std::unique_ptr<Stream>> streams(64);
+    if (!streams[dev]) streams[dev] = std::make_unique<Stream>(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, dev));
+    return *streams[dev];
+  }
+  // events are re-recorded every layer: a small per-thread ring, never destroyed while work may reference them
+  at::cuda::CUDAEvent& event(int i) {
+    static thread_local std::vector<std::unique_ptr<at::cuda::CUDAEvent>> ring(16);
+    auto& e = ring[i & 15];
+    if (!e) e = std::make_unique<at::cuda::CUDAEvent>();
+    return *e;
+  }
+  bool on_, used_ = false;
+  int next_ = 0;
+  Stream main_, side_;
+};
 
 int dt_code(const Tensor& t) {
   if (t.scalar_type() == at::kHalf) return PDT_F16;
@@ -215,18 +275,19 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU, fp32 atomics) ; wgrad
   if (!accumulate) gr[7].zero_();
   Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u); e_dg.colsum = gr[7].data_ptr<float>();
+  WgradLane lane(g_wgrad_mode == 2 || (g_wgrad_mode == 1 && T <= kWgradLaneMaxTokens));
+  lane.run([&] { gemm_tn_into(l2.ddrop, gact, gr[8], accumulate); });
   Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
-  gemm_tn_into(l2.ddrop, gact, gr[8], accumulate);
   // FFN1 dgrad + residual gradient ; wgrad
   Epi e_add; e_add.kind = PDT_EPI_ADD_RES; e_add.res = &l2.dx;
+  lane.run([&] { gemm_tn_into(du, x1, gr[6], accumulate); });
   Tensor dx1 = gemm_nn(du, w[6], e_add);
-  gemm_tn_into(du, x1, gr[6], accumulate);
   // LN1
   LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1),
                        accumulate);
   // attention output projection
+  lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); });
   Tensor dctx = gemm_nn(l1.ddrop, w[2], Epi{});
-  gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate);
   // attention core
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
@@ -245,8 +306,9 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
     colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
   Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
+  lane.run([&] { gemm_tn_into(dqkv, x, gr[0], accumulate); });
   Tensor dx = gemm_nn(dqkv, w[0], e_add2);
-  gemm_tn_into(dqkv, x, gr[0], accumulate);
+  lane.join();  // the layer's gradients are complete on the main stream from here (bucket all-reduce, next layer)
   (void)T; (void)H;
   return dx;
 }
@@ -520,6 +582,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("op_attn_bwd", &op_attn_bwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("ctx"), py::arg("dctx"),
         py::arg("lse"), py::arg("B"), py::arg("S"), py::arg("A"), py::arg("rng_state"), py::arg("p"), py::arg("micro"),
         py::arg("site"), py::arg("dbias") = py::none());
+  m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
+        "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
   m.def("attn_bwd_fuses_dbias", [](int64_t S) { return pdt_attn_bwd_fuses_dbias((int)S) != 0; });
   bind_reducer(m);
   bind_wordpiece(m);
