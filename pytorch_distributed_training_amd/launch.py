@@ -46,13 +46,30 @@ def pick_device(cpu: bool, local_rank: int) -> torch.device:
     return torch.device("cuda", local_rank % torch.cuda.device_count())
 
 
+def default_backend(device: torch.device, env: DistEnv) -> str:
+    """"nccl" (RCCL) when every local rank has a GPU of its own, otherwise "gloo".
+
+    RCCL refuses two ranks on one device, so a rehearsal with more processes than GPUs (e.g. the 2-stage
+    pipeline on a single-GPU box) runs its collectives over gloo: GPU tensors are staged through the host by
+    the callers that support it (``parallel/pp.py``, the bucket reducer)."""
+    if device.type != "cuda":
+        return "gloo"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", env.world_size))
+    if local_world > torch.cuda.device_count():
+        if env.rank == 0:
+            print(f"[launch] {local_world} local ranks share {torch.cuda.device_count()} GPU(s): using the gloo backend "
+                  "(rehearsal mode; RCCL needs one GPU per rank)", flush=True)
+        return "gloo"
+    return "nccl"
+
+
 def init_distributed(cpu: bool = False, backend: Optional[str] = None, timeout_s: int = 1800,
                      env: Optional[DistEnv] = None) -> Tuple[DistEnv, torch.device]:
     """Join (or create) the default process group described by the environment; idempotent."""
     env = env or DistEnv.from_environ()
     device = pick_device(cpu, env.local_rank)
     if env.world_size > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if device.type == "cuda" else "gloo")
+        backend = backend or os.environ.get("PDT_BACKEND") or default_backend(device, env)
         env.export()
         kw = {}
         if backend == "nccl":

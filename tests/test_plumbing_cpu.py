@@ -331,3 +331,18 @@ def test_training_state_resume_is_exact(tmp_path):
     again = [step(m2, o2, s2, i) for i in range(3, 6)]
     assert cont == again
     assert torch.equal(a.master, a2.master)
+
+
+def test_default_backend_choice(monkeypatch):
+    """CPU runs use gloo; the GPU choice (nccl unless ranks outnumber GPUs) needs a device to be exercised."""
+    import torch
+
+    from pytorch_distributed_training_amd import launch
+
+    env = launch.DistEnv(rank=1, local_rank=1, world_size=2)
+    assert launch.default_backend(torch.device("cpu"), env) == "gloo"
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert launch.default_backend(torch.device("cuda", 0), env) == "gloo"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert launch.default_backend(torch.device("cuda", 0), env) == "nccl"
