@@ -44,6 +44,8 @@ def main() -> None:
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,7 +80,17 @@ def main() -> None:
         optimizer.zero_grad()
         return loss
 
-    for i in range(args.warmup):
+    if args.graph:
+        from pytorch_distributed_training_amd.utils.graph import GraphedStep
+
+        graphed = GraphedStep(eng, model, optimizer, warmup=2)
+
+        def step(i: int) -> torch.Tensor:  # noqa: F811 - the same step, replayed from the captured graph
+            loss = graphed([pool[(i * args.accum + a) % len(pool)] for a in range(args.accum)])
+            sched.step()
+            return loss / args.accum
+
+    for i in range(max(args.warmup, 3 if args.graph else 0)):
         step(i)
     _fence(eng)
     t0 = time.perf_counter()
@@ -110,7 +122,8 @@ def main() -> None:
             "tokens_per_s": round(value * args.seq_len, 1),
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
-                       "parallelism": f"dp{world}", "optimizer": "fused AdamW + dynamic loss scale",
+                       "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "optimizer": "fused AdamW + dynamic loss scale",
                        "dropout": 0.1},
         }))
     if world > 1:

@@ -706,8 +706,12 @@ template <typename T>
 static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) {
   const size_t lds = (size_t)4 * 128 * 128 + (size_t)(4 * 128 + ATT_WAVES * 192) * sizeof(float);
   auto kern = attn_bwd_fused128_kernel<T>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static bool configured = false;  // once per process: not a stream operation, keep it out of graph captures
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
   hipLaunchKernelGGL(kern, dim3(a.B * a.A), dim3(ATT_THREADS), lds, stream, a, dbias);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,102 @@
+"""Whole-step HIP graph capture.
+
+A training step of this framework is a fixed sequence of a few hundred to a few thousand kernel launches
+(BERT-large: ~670 per micro-batch).  With large micro-batches the GPU is the bottleneck and the launches hide
+behind it; with the reference's 8-sample micro-batches (/root/reference/test_data_parallelism.py:49,90-93) or with
+small models the host becomes visible.  :class:`GraphedStep` captures forward + backward + optimizer update of a
+fixed-shape batch into ONE hipGraph and replays it, so a step costs one graph launch.
+
+What makes the step capturable by construction:
+
+* every piece of per-step state the kernels read lives in device memory - loss scale and overflow flag, AdamW
+  step counter, learning rate (``FusedAdamW.lr``), the dropout counter (``NativeRuntime.rng_state``) - and is
+  advanced by kernels, never by values baked into launch arguments (the micro-batch index IS a launch argument:
+  it is the position inside the captured accumulation window, identical in every replay, while the in-graph
+  ``rng_state[1] += 1`` gives every replay fresh masks);
+* gradients are born in the arena (no per-step allocation of parameter gradients) and the first micro-batch of a
+  window overwrites, so there is no ``zero_grad`` dependence on host flags across replays;
+* the weight-gradient side stream forks from and joins the capturing stream inside every layer.
+
+The learning-rate schedule stays outside the graph: ``scheduler.step()`` after the call writes the new value into
+the device scalar the captured optimizer kernel reads.  Data-parallel runs are not captured (the bucket
+all-reduces are issued through c10d, which owns its own stream and work objects).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+class GraphedStep:
+    """``loss = step(batch)``: eager for the first ``warmup`` calls, then captured once and replayed.
+
+    ``batch`` is a dict of tensors whose shapes must stay fixed (pad to a fixed length); it is copied into static
+    device buffers before every replay.  ``accum`` micro-batches can be captured as one step by passing a list of
+    ``accum`` dicts.  The returned loss is the static output tensor of the last micro-batch (clone it to keep it).
+    """
+
+    def __init__(self, engine, model, optimizer, warmup: int = 3, step_optimizer: bool = True,
+                 loss_fn: Optional[Callable] = None):
+        if engine.num_processes != 1:
+            raise RuntimeError("GraphedStep captures single-process steps only")
+        if engine.device.type != "cuda":
+            raise RuntimeError("GraphedStep needs a GPU")
+        self.engine, self.model, self.optimizer = engine, model, optimizer
+        self.warmup, self.step_optimizer = max(1, warmup), step_optimizer
+        self.loss_fn = loss_fn
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Optional[list] = None
+        self.static_loss: Optional[torch.Tensor] = None
+        self.calls = 0
+        self._side = torch.cuda.Stream(device=engine.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _window(self) -> torch.Tensor:
+        """One accumulation window on the static batches: the body that is captured."""
+        rt = getattr(self.engine.unwrap_model(self.model), "runtime", None)
+        if rt is not None:
+            rt.rng_state[1:2].add_(1)  # in-graph: every replay draws new dropout masks
+        n = len(self.static)
+        loss = None
+        for mb in self.static:
+            out = self.model(**mb)
+            loss = out.loss if self.loss_fn is None else self.loss_fn(out, mb)
+            self.engine.backward(loss / n if n > 1 else loss)
+        if self.step_optimizer:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        return loss.detach()
+
+    def _load(self, batches) -> None:
+        if self.static is None:
+            self.static = [{k: v.to(self.engine.device).clone() for k, v in b.items()} for b in batches]
+            return
+        if len(batches) != len(self.static):
+            raise ValueError("number of micro-batches changed after capture")
+        for dst, src in zip(self.static, batches):
+            for k, v in src.items():
+                if dst[k].shape != v.shape:
+                    raise ValueError(f"shape of batch[{k!r}] changed: {tuple(v.shape)} vs captured {tuple(dst[k].shape)}")
+                dst[k].copy_(v, non_blocking=True)
+
+    def __call__(self, batch) -> torch.Tensor:
+        batches = batch if isinstance(batch, (list, tuple)) else [batch]
+        self._load(batches)
+        self.calls += 1
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_loss
+        if self.calls <= self.warmup:
+            # eager warm-up on a side stream (lazy initialisation, allocator warm-up), as graph capture requires
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                loss = self._window()
+            torch.cuda.current_stream().wait_stream(self._side)
+            return loss
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._side):
+            self.static_loss = self._window()
+        self.graph = g
+        g.replay()  # capture does not execute: this replay IS the step of this call
+        return self.static_loss

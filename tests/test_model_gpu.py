@@ -148,3 +148,45 @@ def test_engine_training_reduces_loss_fp16_and_bf16():
                 first = tot / n
             last = tot / n
         assert last < first - 0.05, (kw, first, last)
+
+
+def test_graphed_step_matches_eager_and_redraws_dropout():
+    """A step replayed from a captured hipGraph gives the eager loss curve (dropout off), and with dropout on
+    every replay draws new masks although the launch arguments are frozen."""
+    from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+    from pytorch_distributed_training_amd.engine import Engine
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.optim import AdamW
+    from pytorch_distributed_training_amd.utils.graph import GraphedStep
+
+    def run(graphed: bool, model_name: str, lr: float, steps: int):
+        torch.manual_seed(3)
+        eng = Engine(fp16=True, seed=11, init_scale=1024.0)
+        model = build_model(model_name)
+        opt = AdamW(params=model.parameters(), lr=lr)
+        model, opt = eng.prepare(model, opt)
+        model.train()
+        vocab = eng.unwrap_model(model).config.vocab_size
+        batches = [fixed_batch(8, 64, vocab, eng.device, seed=50 + i) for i in range(2)]
+        losses = []
+        if graphed:
+            g = GraphedStep(eng, model, opt, warmup=2)
+            for i in range(steps):
+                losses.append(float(g(batches[i % 2]).item()))
+            assert g.graph is not None
+        else:
+            for i in range(steps):
+                out = model(**batches[i % 2])
+                eng.backward(out.loss)
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(out.loss.item()))
+        return losses
+
+    eager = run(False, "bert-tiny-nodrop", 1e-3, 7)
+    graphed = run(True, "bert-tiny-nodrop", 1e-3, 7)
+    assert max(abs(a - b) for a, b in zip(eager, graphed)) < 2e-3, (eager, graphed)
+    assert graphed[0] != graphed[-1]  # the captured optimizer really updates the weights
+    same_batch = run(True, "bert-tiny", 0.0, 8)  # lr 0, two alternating batches: only the masks change
+    replays = same_batch[3::2]  # replays of batch 1 (calls 4, 6, 8)
+    assert len(set(replays)) == len(replays), same_batch
