@@ -44,6 +44,11 @@ typedef struct PdtGemm {
   // optional fp32 [N]: column sums of the stored C (the bias gradient of the layer that produced C's input)
   // are added here with fp32 atomics, one add per column per 32-row slab of a wave
   float* colsum;
+  // optional fp32 workspace [ws_splits][M][N] for split-K forward / dgrad GEMMs: when non-null (and the epilogue
+  // has no column sums) the K range is cut into ws_splits slices whose fp32 partial tiles are summed by a
+  // second kernel that also applies the epilogue.  pdt_gemm_splits() says how many slices a shape wants.
+  float* ws;
+  int ws_splits;
 } PdtGemm;
 
 // tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves, one barrier per K-tile), 2 = 256x256 ping-pong
@@ -54,6 +59,9 @@ int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]   (out fp32; n multiple of 4)
 int pdt_splitk_reduce(const float* slab, int splits, int64_t n, float* out, int accumulate, void* stream);
 int pdt_gemm_max_splits(void);
+// Number of K slices the dispatcher would like for this NT / NN problem (1 = none): small outputs (few tiles for
+// 256 CUs) with a long K.  The caller allocates ws = fp32 [splits][M][N] and sets g->ws / g->ws_splits.
+int pdt_gemm_splits(int layout, int tile, const PdtGemm* g);
 
 // ---- LayerNorm ----------------------------------------------------------------------------------
 // y = LN(x) * gamma + beta ; stats[row] = {mean, rstd}.  H multiple of 8, H <= 8192.

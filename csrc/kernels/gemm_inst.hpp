@@ -5,6 +5,70 @@
 
 namespace pdt {
 
+// Second kernel of a split-K forward / dgrad GEMM: C = epilogue(sum_s ws[s]) on 8 consecutive columns per thread,
+// with exactly the epilogue code of the GEMM kernels.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(PdtGemm g) {
+  using K = GemmKernel<T, 128, 128, 2, 2, PDT_AKS, PDT_BKS>;
+  const int nch = g.N >> 3;
+  const int64_t total = (int64_t)g.M * nch;
+  const DropKey dk = drop_key(g.rng);
+  const bool dgelu = EPI == EPI_MUL_DGELU;
+  const T* ext = dgelu ? (const T*)g.aux : (const T*)g.res;
+  const int ldx = dgelu ? g.ldaux : g.ldr;
+  const size_t slab = (size_t)g.M * g.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / nch), n = (int)(idx - (int64_t)m * nch) * 8;
+    const float* src = g.ws + (size_t)m * g.N + n;
+    float4v lo = *reinterpret_cast<const float4v*>(src), hi = *reinterpret_cast<const float4v*>(src + 4);
+    for (int s = 1; s < g.splits; ++s) {
+      lo += *reinterpret_cast<const float4v*>(src + s * slab);
+      hi += *reinterpret_cast<const float4v*>(src + s * slab + 4);
+    }
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_TANH)
+      unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.bias + n), bias);
+    short8 x = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (dgelu || EPI == EPI_BIAS_DROP_RES || EPI == EPI_ADD_RES) x = *reinterpret_cast<const short8*>(ext + (size_t)m * ldx + n);
+    K::template epilogue8<EPI>(g, m, n, v, bias, x, dk);
+  }
+}
+
+template <typename T, int EPI>
+static int launch_splitk_epilogue(const PdtGemm& g, hipStream_t stream) {
+  const int64_t total = (int64_t)g.M * (g.N >> 3);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL((splitk_epilogue_kernel<T, EPI>), dim3(grid), dim3(256), 0, stream, g);
+  return (int)hipGetLastError();
+}
+
+// split-K forward / dgrad: the GEMM kernel writes fp32 slabs into g.ws, then the epilogue kernel finishes
+template <typename T, typename LaunchFn>
+static int launch_split(PdtGemm& g, hipStream_t stream, LaunchFn&& launch_gemm) {
+  PdtGemm part = g;
+  part.C = g.ws;
+  part.ldc = g.N;
+  part.epi = PDT_EPI_SLAB_F32;
+  part.colsum = nullptr;
+  if (int e = launch_gemm(part)) return e;
+  switch (g.epi) {
+    case PDT_EPI_PLAIN: return launch_splitk_epilogue<T, EPI_PLAIN>(g, stream);
+#if !PDT_AKS && !PDT_BKS
+    case PDT_EPI_BIAS: return launch_splitk_epilogue<T, EPI_BIAS>(g, stream);
+    case PDT_EPI_BIAS_GELU: return launch_splitk_epilogue<T, EPI_BIAS_GELU>(g, stream);
+    case PDT_EPI_BIAS_DROP_RES: return launch_splitk_epilogue<T, EPI_BIAS_DROP_RES>(g, stream);
+    case PDT_EPI_BIAS_TANH: return launch_splitk_epilogue<T, EPI_BIAS_TANH>(g, stream);
+#endif
+#if !PDT_AKS && PDT_BKS
+    case PDT_EPI_MUL_DGELU: return launch_splitk_epilogue<T, EPI_MUL_DGELU>(g, stream);
+    case PDT_EPI_ADD_RES: return launch_splitk_epilogue<T, EPI_ADD_RES>(g, stream);
+#endif
+    default: return -5;
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_tile(PdtGemm& g, hipStream_t stream) {
   using K = GemmKernel<T, BM, BN, WM, WN, PDT_AKS, PDT_BKS>;
@@ -17,13 +81,17 @@ static int launch_tile(PdtGemm& g, hipStream_t stream) {
   }
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
+  auto launch = [&](PdtGemm& gg) {
+    const int grid = gg.tiles_m * gg.tiles_n * gg.splits;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, stream, gg);
+    return (int)hipGetLastError();
+  };
+  if (g.epi != PDT_EPI_SLAB_F32 && g.ws != nullptr) return launch_split<T>(g, stream, launch);  // splits set by the dispatcher
   if (g.epi != PDT_EPI_SLAB_F32) {
     g.splits = 1;
     g.k_per_split = ((g.K + 63) / 64) * 64;
   }
-  const int grid = g.tiles_m * g.tiles_n * g.splits;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, stream, g);
-  return (int)hipGetLastError();
+  return launch(g);
 }
 
 template <typename T>

@@ -132,6 +132,14 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
   g.drop_scale = keep_scale(e.drop_p);
   g.rng = e.rng;
   g.colsum = e.colsum;
+  // few output tiles + long K: split K over fp32 partial slabs, summed by the epilogue kernel
+  Tensor ws;
+  const int splits = pdt_gemm_splits(layout, tile, &g);
+  if (splits > 1) {
+    ws = at::empty({splits, (int64_t)M, (int64_t)N}, C.options().dtype(at::kFloat));
+    g.ws = ws.data_ptr<float>();
+    g.ws_splits = splits;
+  }
   check(pdt_gemm(dt_code(A), layout, tile, &g, cur_stream()), "gemm");
 }
 
@@ -576,6 +584,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("res"), py::arg("aux"), py::arg("rng_state"), py::arg("drop_p"), py::arg("micro"), py::arg("site"),
         py::arg("tile"), py::arg("colsum") = py::none());
   m.def("op_gemm_tn", &op_gemm_tn);
+  m.def("gemm_splits", [](const std::string& layout, const Tensor& A, const Tensor& B) {
+    PdtGemm g{};
+    g.M = (int)A.size(0); g.K = (int)A.size(1); g.N = (int)(layout == "nt" ? B.size(0) : B.size(1));
+    return pdt_gemm_splits(layout == "nt" ? PDT_GEMM_NT : PDT_GEMM_NN, -1, &g);
+  }, "K slices the dispatcher uses for a forward (nt) / dgrad (nn) GEMM of these operands (1 = one kernel)");
   m.def("op_layernorm_fwd", &op_layernorm_fwd);
   m.def("op_layernorm_bwd", &op_layernorm_bwd);
   m.def("op_attn_fwd", &op_attn_fwd);

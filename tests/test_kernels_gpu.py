@@ -120,8 +120,10 @@ def test_gemm_nn_dgrad(dtype, tile, M, N, K):
     # fused bias gradient: column sums of the stored output, accumulated into an fp32 vector
     cs = torch.ones(N, device="cuda")
     out2 = C().op_gemm("nn", dY, W, 4, None, None, u, None, 0.0, 0, 0, tile, cs)
-    assert torch.equal(out2, out)
-    torch.testing.assert_close(cs, 1 + out.float().sum(0), rtol=2e-3, atol=2e-2)
+    # same values up to the summation order over K (without column sums the dispatcher may split K)
+    rt, at = tol(dtype)
+    torch.testing.assert_close(out2.float(), out.float(), rtol=rt, atol=at)
+    torch.testing.assert_close(cs, 1 + out2.float().sum(0), rtol=2e-3, atol=2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -176,6 +178,49 @@ def test_layernorm_fwd_bwd(dtype, rows, H):
     assert torch.equal(dx2, dx)
     torch.testing.assert_close(ddrop2.float(), dx.float() * mask.float(), rtol=1e-2, atol=1e-3)
     assert rel_err(gbias2, ddrop2.float().sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_split_k_forward_and_dgrad_epilogues(dtype):
+    """Few output tiles + long K: the dispatcher cuts K into fp32 slabs and a second kernel sums them and applies
+    the epilogue.  Every epilogue kind of both layouts against fp32 PyTorch."""
+    torch.manual_seed(21)
+    M, N, K = 384, 256, 4096
+    rt, at = tol(dtype)
+    A = (torch.randn(M, K, device="cuda") * 0.25).to(dtype)
+    W = (torch.randn(N, K, device="cuda") * 0.06).to(dtype)
+    b = (torch.randn(N, device="cuda") * 0.2).to(dtype)
+    res = torch.randn(M, N, device="cuda").to(dtype)
+    ref = A.float() @ W.float().t()
+    assert C().gemm_splits("nt", A, W) > 1
+    out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, -1)
+    torch.testing.assert_close(out.float(), ref, rtol=rt, atol=at)
+    out = C().op_gemm("nt", A, W, 1, b, None, None, None, 0.0, 0, 0, -1)
+    torch.testing.assert_close(out.float(), ref + b.float(), rtol=rt, atol=at)
+    u = torch.empty(M, N, device="cuda", dtype=dtype)
+    g = C().op_gemm("nt", A, W, 2, b, None, u, None, 0.0, 0, 0, -1)
+    torch.testing.assert_close(u.float(), ref + b.float(), rtol=rt, atol=at)
+    torch.testing.assert_close(g.float(), torch.nn.functional.gelu(u.float()), rtol=rt, atol=at)
+    z = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(), 0.0, 0, 0, -1)
+    torch.testing.assert_close(z.float(), ref + b.float() + res.float(), rtol=rt, atol=at)
+    # dropout in the split path uses the same counters as the one-kernel path
+    z1 = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(9, 1), 0.1, 2, 5, -1)
+    z2 = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(9, 1), 0.1, 2, 5, 0)
+    dropped1 = (z1.float() - res.float()).abs() < 1e-6
+    dropped2 = (z2.float() - res.float()).abs() < 1e-6
+    assert torch.equal(dropped1, dropped2) and 0.05 < dropped1.float().mean().item() < 0.15
+    # dgrad layout
+    Wn = (torch.randn(K, N, device="cuda") * 0.06).to(dtype)
+    refn = A.float() @ Wn.float()
+    out = C().op_gemm("nn", A, Wn, 0, None, None, None, None, 0.0, 0, 0, -1)
+    torch.testing.assert_close(out.float(), refn, rtol=rt, atol=at)
+    out = C().op_gemm("nn", A, Wn, 5, None, res, None, None, 0.0, 0, 0, -1)
+    torch.testing.assert_close(out.float(), refn + res.float(), rtol=rt, atol=at)
+    uu = torch.randn(M, N, device="cuda").to(dtype)
+    out = C().op_gemm("nn", A, Wn, 4, None, None, uu, None, 0.0, 0, 0, -1)
+    uf = uu.float().requires_grad_()
+    torch.nn.functional.gelu(uf).sum().backward()
+    torch.testing.assert_close(out.float(), refn * uf.grad, rtol=rt, atol=at)
 
 
 # ------------------------------------------------------------------------------------------ attention
