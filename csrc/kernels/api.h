@@ -59,6 +59,8 @@ int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]   (out fp32; n multiple of 4)
 int pdt_splitk_reduce(const float* slab, int splits, int64_t n, float* out, int accumulate, void* stream);
 int pdt_gemm_max_splits(void);
+// slabs a TN (weight-gradient) GEMM of this shape writes (g->splits > 0: that many); size C accordingly
+int pdt_gemm_tn_splits(int tile, const PdtGemm* g);
 // Number of K slices the dispatcher would like for this NT / NN problem (1 = none): small outputs (few tiles for
 // 256 CUs) with a long K.  The caller allocates ws = fp32 [splits][M][N] and sets g->ws / g->ws_splits.
 int pdt_gemm_splits(int layout, int tile, const PdtGemm* g);

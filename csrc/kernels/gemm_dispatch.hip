@@ -18,9 +18,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     reinterpret_cast<float4v*>(out)[i] = s;
   }
 }
+
+// tile variant for a shape (tile >= 0: the caller's choice)
+static int choose_tile(int layout, int tile, const PdtGemm* g) {
+  if (tile >= 0) return tile;
+  // measured on MI355X (bench/gemm_bench.py, BERT-large shapes): the ping-pong 256x256 kernel wins for
+  // forward / dgrad once its tiles fill most of the 256 CUs, and for weight gradients (split-K fills the
+  // CUs whatever the tile count) as soon as the output holds one 256x256 tile; small problems use 128x128
+  // tiles at two workgroups per CU
+  const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
+  // (weight gradients of short micro-batches, K = tokens <= 2048, have too few K-tiles per slice for the
+  // 256x256 kernel: 128x128 tiles measured 10-30 % faster there)
+  if (layout == PDT_GEMM_TN) return (g->M >= 256 && g->N >= 256 && g->K > 2048) ? 2 : 0;
+  return t256 >= 128 ? 2 : 0;
+}
+
+// K split of a weight gradient: fills g->splits / g->k_per_split (g->splits <= 0: choose)
+static void plan_tn(int tile, PdtGemm* g) {
+  const int bt = tile == 0 ? 128 : 256;
+  const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
+  const int ktiles = (g->K + 63) / 64;
+  if (g->splits <= 0) {
+    // one full round of workgroups: tiles * splits <= CUs (x2 for the 128x128 kernel, 2 workgroups per CU)
+    const int target = tile == 0 ? 2 * kNumCU : kNumCU;
+    int s = target / tiles;
+    s = s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s);
+    if (s > ktiles) s = ktiles;
+    g->splits = s;
+  }
+  const int kt_per = (ktiles + g->splits - 1) / g->splits;
+  g->k_per_split = kt_per * 64;
+  g->splits = (ktiles + kt_per - 1) / kt_per;  // no empty split
+}
 }  // namespace pdt
 
 extern "C" int pdt_gemm_max_splits(void) { return pdt::kMaxSplits; }
+
+// number of fp32 slabs a weight-gradient GEMM of this shape will write (what the caller must allocate)
+extern "C" int pdt_gemm_tn_splits(int tile, const PdtGemm* g) {
+  PdtGemm c = *g;
+  pdt::plan_tn(pdt::choose_tile(PDT_GEMM_TN, tile, &c), &c);
+  return c.splits;
+}
 
 // Forward / dgrad GEMMs whose output has few tiles but whose K is long (e.g. 1024 tokens x 1024 outputs x 4096)
 // leave most CUs idle with one workgroup per output tile: 128x128 tiles fill 2 x 256 workgroup slots, so cut K
@@ -50,33 +89,10 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
   const int64_t a_bytes = 2ll * (layout == PDT_GEMM_TN ? (int64_t)g->K * g->lda : 256ll * g->lda);
   const int64_t b_bytes = 2ll * (layout == PDT_GEMM_NT ? 256ll * g->ldb : (int64_t)g->K * g->ldb);
   if (a_bytes >= 0x7FFF0000ll || b_bytes >= 0x7FFF0000ll) return -4;
-  if (tile < 0) {
-    // measured on MI355X (bench/gemm_bench.py, BERT-large shapes): the ping-pong 256x256 kernel wins for
-    // forward / dgrad once its tiles fill most of the 256 CUs, and for weight gradients (split-K fills the
-    // CUs whatever the tile count) as soon as the output holds one 256x256 tile; small problems use 128x128
-    // tiles at two workgroups per CU
-    const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-    // (weight gradients of short micro-batches, K = tokens <= 2048, have too few K-tiles per slice for the
-    // 256x256 kernel: 128x128 tiles measured 10-30 % faster there)
-    if (layout == PDT_GEMM_TN) tile = (g->M >= 256 && g->N >= 256 && g->K > 2048) ? 2 : 0;
-    else tile = t256 >= 128 ? 2 : 0;
-  }
+  tile = choose_tile(layout, tile, g);
   if (layout == PDT_GEMM_TN) {
     if (g->epi != PDT_EPI_SLAB_F32) return -5;
-    const int bt = tile == 0 ? 128 : 256;
-    const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
-    const int ktiles = (g->K + 63) / 64;
-    if (g->splits <= 0) {
-      // one full round of workgroups: tiles * splits <= CUs (x2 for the 128x128 kernel, 2 workgroups per CU)
-      const int target = tile == 0 ? 2 * kNumCU : kNumCU;
-      int s = target / tiles;
-      s = s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s);
-      if (s > ktiles) s = ktiles;
-      g->splits = s;
-    }
-    const int kt_per = (ktiles + g->splits - 1) / g->splits;
-    g->k_per_split = kt_per * 64;
-    g->splits = (ktiles + kt_per - 1) / kt_per;  // no empty split
+    plan_tn(tile, g);
     return pdt_gemm_tn(dtype, tile, g, stream);
   }
   // each operand layout carries the epilogues of its role (forward: bias family; data gradient: GELU-grad

@@ -166,13 +166,15 @@ void gemm_tn_into(const Tensor& A, const Tensor& B, Tensor& G, bool accumulate, 
   chk16(A, "A"); chk16(B, "B"); chkf32(G, "G");
   const int K = (int)A.size(0), M = (int)A.size(1), N = (int)B.size(1);
   TORCH_CHECK(B.size(0) == K && G.size(0) == M && G.size(1) == N, "gemm_tn: shape mismatch");
-  Tensor slab = at::empty({(int64_t)pdt_gemm_max_splits() * M * N}, G.options());
   PdtGemm g{};
-  g.A = A.data_ptr(); g.B = B.data_ptr(); g.C = slab.data_ptr();
+  g.A = A.data_ptr(); g.B = B.data_ptr();
   g.M = M; g.N = N; g.K = K;
   g.lda = (int)A.stride(0); g.ldb = (int)B.stride(0); g.ldc = N;
   g.epi = PDT_EPI_SLAB_F32;
   g.splits = splits;
+  g.splits = pdt_gemm_tn_splits(tile, &g);
+  Tensor slab = at::empty({(int64_t)g.splits * M * N}, G.options());
+  g.C = slab.data_ptr();
   check(pdt_gemm(dt_code(A), PDT_GEMM_TN, tile, &g, cur_stream()), "gemm_tn");
   check(pdt_splitk_reduce(slab.data_ptr<float>(), g.splits, (int64_t)M * N, G.data_ptr<float>(), accumulate ? 1 : 0,
                           cur_stream()), "splitk_reduce");
