@@ -141,6 +141,43 @@ __device__ __forceinline__ GeluParts gelu_parts(float u) {
   r.pdf = 0.3989422804014327f * e;
   return r;
 }
+// Two elements at a time on <2 x float>: the multiply/add chain becomes packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32, two lanes' worth of math per issue); exp and rcp stay scalar.
+__device__ __forceinline__ void gelu_parts2(float2v u, float2v& cdf, float2v& pdf) {
+  const float2v x = float2v{fabsf(u.x), fabsf(u.y)} * 0.70710678118654752f;
+  const float2v nx2 = -(x * x) * 1.4426950408889634f;
+  const float2v e = float2v{__builtin_amdgcn_exp2f(nx2.x), __builtin_amdgcn_exp2f(nx2.y)};
+  const float2v d = x * 0.3275911f + 1.0f;
+  const float2v t = float2v{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  float2v p = t * 1.061405429f + -1.453152027f;
+  p = t * p + 1.421413741f;
+  p = t * p + -0.284496736f;
+  p = t * p + 0.254829592f;
+  const float2v h = (p * t) * (e * 0.5f);  // 0.5 * erfc(|x|)
+  cdf = float2v{u.x >= 0.f ? 1.0f - h.x : h.x, u.y >= 0.f ? 1.0f - h.y : h.y};
+  pdf = e * 0.3989422804014327f;
+}
+// v[i] = gelu(v[i]) / v[i] *= gelu'(u[i]) on 8 values (the unit of the GEMM epilogues)
+__device__ __forceinline__ void gelu8(float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    float2v c, d;
+    const float2v u = float2v{v[i], v[i + 1]};
+    gelu_parts2(u, c, d);
+    const float2v r = u * c;
+    v[i] = r.x; v[i + 1] = r.y;
+  }
+}
+__device__ __forceinline__ void mul_gelu_grad8(float (&v)[8], const float (&u8)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    float2v c, d;
+    const float2v u = float2v{u8[i], u8[i + 1]};
+    gelu_parts2(u, c, d);
+    const float2v r = float2v{v[i], v[i + 1]} * (u * d + c);
+    v[i] = r.x; v[i + 1] = r.y;
+  }
+}
 __device__ __forceinline__ float gelu_f(float u) { return u * gelu_parts(u).cdf; }
 __device__ __forceinline__ float gelu_grad_f(float u) {
   const GeluParts g = gelu_parts(u);

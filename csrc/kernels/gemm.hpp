@@ -139,16 +139,14 @@ struct GemmKernel {
     }
     if (epi == EPI_BIAS_GELU) {
       *reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n) = pack8<T>(v);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+      gelu8(v);
     } else if (epi == EPI_BIAS_TANH) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
     } else if (epi == EPI_MUL_DGELU) {
       float u[8];
       unpack8<T>(ext, u);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(u[i]);
+      mul_gelu_grad8(v, u);
     }
     if (epi == EPI_BIAS_DROP_RES && g.drop_thr != 0) {
       const uint32_t keep = drop_keep8(dk, ((uint64_t)m * g.N + n) >> 3, g.drop_thr);
