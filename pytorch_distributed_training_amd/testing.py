@@ -35,22 +35,31 @@ def _entry(rank: int, world: int, port: int, fn: Callable, args: tuple, outdir: 
 
 def run_distributed(fn: Callable, world: int = 2, args: tuple = (), backend: str = "gloo") -> List[Any]:
     """Spawn `world` processes, run ``fn(rank, world, *args)`` in each, return the per-rank results."""
-    with tempfile.TemporaryDirectory() as d:
-        port = find_free_port()
-        try:
-            mp.spawn(_entry, args=(world, port, fn, args, d, backend), nprocs=world, join=True)
-        except Exception:
-            msgs = []
+    # the rendezvous port is probed, released and then bound by rank 0: another process can take it in between
+    # (or it can still be in TIME_WAIT), so a rendezvous failure is retried on a fresh port
+    transient = ("address already in use", "eaddrinuse", "connection refused", "connection reset", "failed to bind")
+    for attempt in range(3):
+        with tempfile.TemporaryDirectory() as d:
+            port = find_free_port()
+            try:
+                mp.spawn(_entry, args=(world, port, fn, args, d, backend), nprocs=world, join=True)
+            except Exception as exc:
+                msgs = [str(exc)]
+                for r in range(world):
+                    p = os.path.join(d, f"r{r}.pkl")
+                    if os.path.exists(p):
+                        kind, val = pickle.load(open(p, "rb"))
+                        if kind == "err":
+                            msgs.append(f"--- rank {r} ---\n{val}")
+                text = "\n".join(msgs)
+                if attempt < 2 and any(t in text.lower() for t in transient):
+                    continue
+                raise RuntimeError("distributed test failed:\n" + text)
+            out = []
             for r in range(world):
-                p = os.path.join(d, f"r{r}.pkl")
-                if os.path.exists(p):
-                    kind, val = pickle.load(open(p, "rb"))
-                    if kind == "err":
-                        msgs.append(f"--- rank {r} ---\n{val}")
-            raise RuntimeError("distributed test failed:\n" + "\n".join(msgs))
-        out = []
-        for r in range(world):
-            kind, val = pickle.load(open(os.path.join(d, f"r{r}.pkl"), "rb"))
-            assert kind == "ok"
-            out.append(val)
-        return out
+                kind, val = pickle.load(open(os.path.join(d, f"r{r}.pkl"), "rb"))
+                assert kind == "ok"
+                out.append(val)
+            return out
+    raise RuntimeError("unreachable")
+
