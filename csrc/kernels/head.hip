@@ -7,16 +7,17 @@ namespace pdt {
 
 constexpr int HEAD_MAX_C = 8;
 
+constexpr int HEAD_FWD_WAVES = 16;  // one workgroup (fixed-order, deterministic loss sum); one sample per wave and pass
 template <typename T>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ pooled, const float* __restrict__ W,
+__global__ __launch_bounds__(HEAD_FWD_WAVES * 64) void head_fwd_kernel(const T* __restrict__ pooled, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const int64_t* __restrict__ labels,
                                                        float* __restrict__ logits, float* __restrict__ loss, int B, int H,
                                                        int C, float drop_scale, uint32_t drop_thr, RngArgs rng) {
-  __shared__ float wloss[4];
+  __shared__ float wloss[HEAD_FWD_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   DropKey dk = drop_key(rng);
   float my_loss = 0.f;
-  for (int b = wave; b < B; b += 4) {
+  for (int b = wave; b < B; b += HEAD_FWD_WAVES) {
     float dot[HEAD_MAX_C];
 #pragma unroll
     for (int c = 0; c < HEAD_MAX_C; ++c) dot[c] = 0.f;
@@ -58,7 +59,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ poo
   }
   if (lane == 0) wloss[wave] = my_loss;
   __syncthreads();
-  if (threadIdx.x == 0 && loss) loss[0] = (wloss[0] + wloss[1] + wloss[2] + wloss[3]) / B;
+  if (threadIdx.x == 0 && loss) {
+    float t = 0.f;
+    for (int w = 0; w < HEAD_FWD_WAVES; ++w) t += wloss[w];
+    loss[0] = t / B;
+  }
 }
 
 // grid = ceil(H/256) blocks; every block recomputes the B x C logit gradients into LDS (cheap) and then
@@ -129,7 +134,7 @@ extern "C" int pdt_head_fwd(int dtype, const void* pooled, const float* W, const
                             PdtRng rng, void* stream) {
   if ((H & 7) || C < 1 || C > HEAD_MAX_C || B <= 0) return -3;
 #define PDT_GO(TT)                                                                                              \
-  hipLaunchKernelGGL(head_fwd_kernel<TT>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const TT*)pooled, W, bias, \
+  hipLaunchKernelGGL(head_fwd_kernel<TT>, dim3(1), dim3(HEAD_FWD_WAVES * 64), 0, (hipStream_t)stream, (const TT*)pooled, W, bias, \
                      labels, logits, loss, B, H, C, drop_scale, drop_thr, rng)
   if (dtype == PDT_F16) PDT_GO(_Float16); else PDT_GO(__bf16);
 #undef PDT_GO
