@@ -138,7 +138,8 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] += bias[i];
     }
     if (epi == EPI_BIAS_GELU) {
-      *reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n) = pack8<T>(v);
+      // the pre-activation is not read again before the backward pass: keep it out of the caches
+      __builtin_nontemporal_store(pack8<T>(v), reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n));
       gelu8(v);
     } else if (epi == EPI_BIAS_TANH) {
 #pragma unroll
