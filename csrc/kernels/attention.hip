@@ -64,12 +64,12 @@ __device__ __forceinline__ uint32_t attn_thr_hi(uint32_t thr) { return (thr > 65
 template <typename T>
 __device__ __forceinline__ void dma_image128(char* img, const T* src, int stride, int nvalid, int tid, int wave) {
   const uint32_t bytes = nvalid > 0 ? (uint32_t)(((size_t)(nvalid - 1) * stride + HD) * 2) : 0u;
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, bytes, 0x00020000);
+  const int4v rsrc = pdt_make_rsrc(src, bytes);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int idx = u * ATT_THREADS + tid, row = idx >> 3, c = (idx & 7) ^ (row & 6);
     const uint32_t off = row < nvalid ? ((uint32_t)row * stride + c * 8) * 2u : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(img + (u * ATT_THREADS + wave * 64) * 16), 16, off, 0, 0, 0);
+    pdt_lds_dma16(rsrc, img + (u * ATT_THREADS + wave * 64) * 16, off);
   }
 }
 // rows x0..x0+15 as an MFMA A operand: lane -> row x0+(lane&15), k = 8*(lane>>4)+j of k-step ks (k = head dim)
@@ -480,24 +480,38 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   const bool drop = a.drop_thr != 0;
   const int r0 = wave * 16;  // this wave's query rows in the dQ sweep, its keys in the dK/dV sweep
 
-  dma_image128<T>(img0, base + a.H, ld, S, tid, wave);      // K
-  dma_image128<T>(img1, base + 2 * a.H, ld, S, tid, wave);  // V
-  dma_image128<T>(img2, base, ld, S, tid, wave);            // Q
-  dma_image128<T>(img3, dob, a.H, S, tid, wave);            // dO
-  for (int i = tid; i < SMAX; i += ATT_THREADS) {
-    mbias[i] = (i < S && a.mask[(size_t)b * S + i] != 0) ? 0.f : -INFINITY;
-    // log2-domain lse; +inf for the padding rows makes their recomputed probabilities exactly 0
-    lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] * LOG2E : INFINITY;
-    seed_s[i] = attn_row_seed(dk, bh, i);
-  }
-  // the wave's own query rows of Q and dO straight from global memory (B-operand fragments), and
-  // delta = rowsum(dO * O)
+  // Issue order = completion order (vmcnt is in order): the wave's own rows and the per-row scalars first, then the
+  // K / V images the dQ sweep needs, then the Q / dO images, which are only needed by the dK/dV sweep and keep
+  // landing while the dQ sweep runs (s_waitcnt vmcnt(4) leaves exactly their four pieces outstanding).
+  // own query rows of Q and dO straight from global memory (B-operand fragments), and delta = rowsum(dO * O)
   short8 qf0, qf1, df0, df1;
   {
     const int q = r0 + lm, qc = min(q, S - 1);
     qf0 = gfrag<T>(base, qc, ld, 0, lane); qf1 = gfrag<T>(base, qc, ld, 1, lane);
     df0 = gfrag<T>(dob, qc, a.H, 0, lane); df1 = gfrag<T>(dob, qc, a.H, 1, lane);
     const short8 of0 = gfrag<T>(ob, qc, a.H, 0, lane), of1 = gfrag<T>(ob, qc, a.H, 1, lane);
+    // raw per-row scalars: loaded here, converted after the DMA block so that no wait sits in front of it
+    int mask_raw = 0;
+    float lse_raw = 0.f;
+    if (tid < S) {
+      mask_raw = a.mask[(size_t)b * S + tid];
+      lse_raw = a.lse[(size_t)bh * S + tid];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    dma_image128<T>(img0, base + a.H, ld, S, tid, wave);      // K
+    dma_image128<T>(img1, base + 2 * a.H, ld, S, tid, wave);  // V
+    asm volatile("" ::: "memory");
+    dma_image128<T>(img2, base, ld, S, tid, wave);            // Q
+    dma_image128<T>(img3, dob, a.H, S, tid, wave);            // dO
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < SMAX) {
+      mbias[tid] = (tid < S && mask_raw != 0) ? 0.f : -INFINITY;
+      // log2-domain lse; +inf for the padding rows makes their recomputed probabilities exactly 0
+      lse_s[tid] = tid < S ? lse_raw * LOG2E : INFINITY;
+      seed_s[tid] = attn_row_seed(dk, bh, tid);
+    }
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -509,20 +523,24 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
     }
     if (g == 0) del_s[q] = d;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // own rows, scalars, K and V have landed and this wave's LDS writes are done; Q / dO may still be in flight
+  // (a raw barrier: __syncthreads() would drain vmcnt to 0)
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   PDT_STAMP(1);
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   PDT_STAMP(2);
 
   // ---- dQ for query rows r0..r0+15 (keys on the sweep axis)
+  float4v dq[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
   if (r0 < S) {
     const int q = r0 + lm;
     // exp2(score2 + mask - lse2q) = p * scale: the softmax scale of dS is folded into the exponent
     const float lse2q = lse_s[q] - __log2f(a.scale), ndelta = -del_s[q];
     const uint32_t rseed = seed_s[q], kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
-    float4v dq[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
       if (pb < npb) {
@@ -550,6 +568,13 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
         for (int db = 0; db < 4; ++db) dq[db] = Half16<T>::mfma(tr_frag(img0, pb * 32, db, lane), dsf, dq[db]);
       }
     }
+  }
+  // the Q / dO images are needed from here on: everything this wave issued has landed (the dQ sweep issued no
+  // memory operation), then every wave's share has
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (r0 < S) {
+    const int q = r0 + lm;
     if (q < S) {
       T* out = (T*)a.dqkv + ((size_t)b * S + q) * ld + h * HD;
 #pragma unroll

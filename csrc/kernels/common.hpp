@@ -18,6 +18,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short short4r __attribute__((__vector_size__(4 * sizeof(short))));
 
 #define PDT_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane from global memory straight into LDS) -------------
+// Issued through inline asm on purpose.  With the compiler builtin, the waitcnt-insertion pass knows an LDS-DMA
+// is in flight and, having no alias information for it, puts `s_waitcnt vmcnt(0)` in front of every later LDS
+// access it treats as a possible store - which includes every ds_read_b64_tr_b16 - so each K-tile of a kernel
+// with transposed fragment reads drained its whole prefetch queue.  All kernels here order DMA data with their
+// own counted `s_waitcnt vmcnt(N)` + barrier, so the compiler does not need to (and must not) know.
+// Untracked VMEM operations only make the compiler's own vmcnt waits for ordinary loads more conservative
+// (the counter is in order).
+// Buffer resource: {base[31:0], base[47:32], num_records (bytes), flags}; offsets >= num_records read as zeros.
+__device__ __forceinline__ int4v pdt_make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  return int4v{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// lds_dst: wave-uniform LDS address of the 1-KiB piece (lane l lands at lds_dst + 16*l); voff: per-lane byte offset
+__device__ __forceinline__ void pdt_lds_dma16(int4v rsrc, const void* lds_dst, uint32_t voff) {
+  const uint32_t lds_addr = (uint32_t)(size_t)PDT_LDS_PTR(lds_dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
 
 // dtype codes shared with the host side
 enum : int { DT_F16 = 0, DT_BF16 = 1 };

@@ -51,7 +51,7 @@ struct GemmKernel {
   struct Loader {
     uint32_t off[PASSES];    // byte offset of this lane's 16 B inside the operand's buffer window
     uint32_t kcol[PASSES];   // (K-contiguous only) k index of the chunk inside the K-tile
-    __amdgpu_buffer_rsrc_t rsrc;
+    int4v rsrc;
     uint32_t kstep;          // bytes to advance per K-tile
 
     __device__ __forceinline__ void init(const T* X, int ld, int xdim, int x0, int kb, int klen, int tid) {
@@ -72,7 +72,7 @@ struct GemmKernel {
         base = X;
         records = 0;
       }
-      rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, records, 0x00020000);
+      rsrc = pdt_make_rsrc(base, records);
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int pos = p * NT * 16 + tid * 16;
@@ -98,7 +98,7 @@ struct GemmKernel {
       for (int p = 0; p < PASSES; ++p) {
         uint32_t o = off[p] + (uint32_t)kt * kstep;
         if (!KS) o = ((int)(kcol[p] + kt * BK) < klen) ? o : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, PDT_LDS_PTR(dst + p * NT * 16 + wave * 1024), 16, o, 0, 0, 0);
+        pdt_lds_dma16(rsrc, dst + p * NT * 16 + wave * 1024, o);
       }
     }
   };
