@@ -30,12 +30,15 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 // (the counter is in order).
 // Buffer resource: {base[31:0], base[47:32], num_records (bytes), flags}; offsets >= num_records read as zeros.
 __device__ __forceinline__ int4v pdt_make_rsrc(const void* base, uint32_t bytes) {
+  // (readfirstlane: the descriptor must live in SGPRs whatever the divergence analysis thinks of `base`)
   const uint64_t a = (uint64_t)base;
-  return int4v{(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+  return int4v{__builtin_amdgcn_readfirstlane((int)(uint32_t)a),
+               __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xFFFFu)),
+               __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
 }
 // lds_dst: wave-uniform LDS address of the 1-KiB piece (lane l lands at lds_dst + 16*l); voff: per-lane byte offset
 __device__ __forceinline__ void pdt_lds_dma16(int4v rsrc, const void* lds_dst, uint32_t voff) {
-  const uint32_t lds_addr = (uint32_t)(size_t)PDT_LDS_PTR(lds_dst);
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)PDT_LDS_PTR(lds_dst));
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(lds_addr), "v"(voff), "s"(rsrc));
 }
