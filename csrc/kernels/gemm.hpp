@@ -283,7 +283,8 @@ struct GemmKernel {
     const int ntiles = g.tiles_m * g.tiles_n;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id / ntiles, t = id % ntiles;
-    const int tm = t / g.tiles_n, tn = t % g.tiles_n;
+    int tm, tn;
+    tile_coords(t, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int kb = split * g.k_per_split;
     const int klen = min(g.K - kb, g.k_per_split);

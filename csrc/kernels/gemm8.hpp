@@ -70,7 +70,8 @@ struct Gemm8 {
     const int ntiles = g.tiles_m * g.tiles_n;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id / ntiles, t_ = id % ntiles;
-    const int tm = t_ / g.tiles_n, tn = t_ % g.tiles_n;
+    int tm, tn;
+    tile_coords(t_, g.tiles_m, g.tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
     const int kb = split * g.k_per_split;
     const int klen = min(g.K - kb, g.k_per_split);
