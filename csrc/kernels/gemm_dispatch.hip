@@ -22,15 +22,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // tile variant for a shape (tile >= 0: the caller's choice)
 static int choose_tile(int layout, int tile, const PdtGemm* g) {
   if (tile >= 0) return tile;
-  // measured on MI355X (bench/gemm_bench.py, BERT-large shapes): the ping-pong 256x256 kernel wins for
-  // forward / dgrad once its tiles fill most of the 256 CUs, and for weight gradients (split-K fills the
-  // CUs whatever the tile count) as soon as the output holds one 256x256 tile; small problems use 128x128
-  // tiles at two workgroups per CU
+  // measured on MI355X (bench/gemm_bench.py, BERT-large shapes, 1024..32768 tokens): the ping-pong 256x256
+  // kernel wins for forward / dgrad once its tiles fill at least 3/4 of the 256 CUs (at exactly 128 tiles the
+  // 128x128 kernel, two workgroups per CU, is 20-30 % ahead); for weight gradients (split-K fills the CUs
+  // whatever the tile count) it wins from K = 8192 tokens on, for a 1024x1024 output only from 32768
   const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-  // (weight gradients of short micro-batches, K = tokens <= 2048, have too few K-tiles per slice for the
-  // 256x256 kernel: 128x128 tiles measured 10-30 % faster there)
-  if (layout == PDT_GEMM_TN) return (g->M >= 256 && g->N >= 256 && g->K > 2048) ? 2 : 0;
-  return t256 >= 128 ? 2 : 0;
+  if (layout == PDT_GEMM_TN)
+    return (g->M >= 256 && g->N >= 256 && g->K >= 8192 && (t256 >= 32 || g->K >= 32768)) ? 2 : 0;
+  return t256 >= 192 ? 2 : 0;
 }
 
 // K split of a weight gradient: fills g->splits / g->k_per_split (g->splits <= 0: choose)
@@ -70,7 +69,7 @@ extern "C" int pdt_gemm_splits(int layout, int tile, const PdtGemm* g) {
   using namespace pdt;
   if (layout == PDT_GEMM_TN || g->colsum != nullptr || g->epi == PDT_EPI_SLAB_F32) return 1;
   const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-  if (tile > 0 || (tile < 0 && t256 >= 128)) return 1;  // only the 128x128 kernel takes this path
+  if (tile > 0 || (tile < 0 && t256 >= 192)) return 1;  // only the 128x128 kernel takes this path
   const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128);
   const int ktiles = (g->K + 63) / 64;
   int s = (int)((2 * kNumCU) / t128);
