@@ -44,6 +44,9 @@ def main() -> None:
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="single GPU only: run the data-parallel machinery anyway (1-rank RCCL group, every bucket "
+                         "all-reduce really issued on RCCL's stream) to see what the gradient path costs besides the wire")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()
@@ -52,6 +55,14 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     comm = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[args.comm_dtype]
+    if args.rehearse_dp:
+        if world != 1:
+            raise SystemExit("--rehearse-dp is a single-GPU rehearsal")
+        os.environ["PDT_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm)
     if eng.device.type != "cuda":
         raise SystemExit("bench.py needs a GPU")
@@ -59,6 +70,11 @@ def main() -> None:
     model = build_model(args.model)
     optimizer = AdamW(params=model.parameters(), lr=2e-5, correct_bias=True)
     model, optimizer = eng.prepare(model, optimizer)
+    if args.rehearse_dp:
+        from pytorch_distributed_training_amd.parallel.dp import DataParallel
+
+        model = DataParallel(model, model.arena, None, comm)
+        eng._models[-1] = model
     sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
     model.train()
     micro = args.batch // args.accum
@@ -122,11 +138,12 @@ def main() -> None:
             "tokens_per_s": round(value * args.seq_len, 1),
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
-                       "parallelism": f"dp{world}", "hip_graph": bool(args.graph),
+                       "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
+                       "hip_graph": bool(args.graph),
                        "optimizer": "fused AdamW + dynamic loss scale",
                        "dropout": 0.1},
         }))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
