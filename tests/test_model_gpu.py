@@ -190,3 +190,28 @@ def test_graphed_step_matches_eager_and_redraws_dropout():
     same_batch = run(True, "bert-tiny", 0.0, 8)  # lr 0, two alternating batches: only the masks change
     replays = same_batch[3::2]  # replays of batch 1 (calls 4, 6, 8)
     assert len(set(replays)) == len(replays), same_batch
+
+
+def test_bench_contract_json_line():
+    """bench.py prints exactly one JSON line with the fields the benchmark driver reads."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--model", "bert-tiny",
+                        "--batch", "8", "--seq-len", "64"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["unit"] == "samples/s" and d["value"] > 0
+    assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3 / 1000)) / d["value"] < 1e-2
+    for key in ("model", "global_batch", "seq_len", "parallelism"):
+        assert key in d["config"], key
