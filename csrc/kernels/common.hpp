@@ -36,7 +36,9 @@ __device__ __forceinline__ int4v pdt_make_rsrc(const void* base, uint32_t bytes)
                __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xFFFFu)),
                __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
 }
-// lds_dst: wave-uniform LDS address of the 1-KiB piece (lane l lands at lds_dst + 16*l); voff: per-lane byte offset
+// lds_dst: wave-uniform LDS address of the 1-KiB piece (lane l lands at lds_dst + 16*l); voff: per-lane byte offset.
+// M0 (the LDS base of the transfer) is written inside the asm; it is a reserved register the compiler only sets
+// right in front of its own M0 users (LDS-DMA builtins, movrel indexing), none of which these kernels contain.
 __device__ __forceinline__ void pdt_lds_dma16(int4v rsrc, const void* lds_dst, uint32_t voff) {
   const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)PDT_LDS_PTR(lds_dst));
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
