@@ -109,6 +109,12 @@ def main() -> None:
     for i in range(max(args.warmup, 3 if args.graph else 0)):
         step(i)
     _fence(eng)
+    # two events per backward around the waits for the bucket collectives: reports how much of the gradient
+    # communication backward did not hide (diagnostic only, nothing is synchronised inside the timed region)
+    timed_dp = hasattr(model, "comm_exposed_ms")
+    if timed_dp:
+        model.measure_exposed = True
+        model.comm_exposed_ms()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -118,6 +124,8 @@ def main() -> None:
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    exposed = model.comm_exposed_ms() if timed_dp else None
+    exposed = round(exposed, 3) if exposed is not None else None
     global_batch = args.batch * world
     value = global_batch * args.steps / dt
     if eng.is_main_process:
@@ -136,6 +144,7 @@ def main() -> None:
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
             "final_loss": float(loss.item()) * args.accum,
             "tokens_per_s": round(value * args.seq_len, 1),
+            "comm_exposed_ms_per_step": exposed,
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),

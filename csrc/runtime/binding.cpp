@@ -84,9 +84,23 @@ int dt_code(const Tensor& t) {
   if (t.scalar_type() == at::kBFloat16) return PDT_BF16;
   TORCH_CHECK(false, "expected a float16/bfloat16 tensor, got ", t.scalar_type());
 }
+// Serialized debug mode (PDT_DEBUG_SYNC=1 or set_debug_sync(true)): the device is drained after every native
+// launch, so an asynchronous fault or a sticky error is reported at the op that caused it instead of at the
+// next unrelated synchronisation point.  Kernels of different streams never overlap in this mode, which also
+// makes it the A/B switch for a suspected stream-ordering bug (a failure that disappears here is an ordering bug).
+bool g_debug_sync = [] {
+  const char* e = std::getenv("PDT_DEBUG_SYNC");
+  return e && e[0] == '1';
+}();
+int64_t g_debug_sync_count = 0;
 void check(int err, const char* what) {
   TORCH_CHECK(err == 0, "pdt kernel launch failed in ", what, ": code ", err,
               err < 0 ? " (argument check)" : " (hipError_t)");
+  if (g_debug_sync) {
+    const hipError_t e = hipDeviceSynchronize();
+    ++g_debug_sync_count;
+    TORCH_CHECK(e == hipSuccess, "pdt kernel faulted in ", what, ": ", hipGetErrorString(e));
+  }
 }
 void chk16(const Tensor& t, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, " must be on the GPU");
@@ -599,6 +613,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("site"), py::arg("dbias") = py::none());
   m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
         "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
+  m.def("set_debug_sync", [](bool on) { g_debug_sync = on; },
+        "drain the device after every native launch and report a fault at the op that caused it");
+  m.def("debug_sync_count", [] { return g_debug_sync_count; });
   m.def("attn_bwd_fuses_dbias", [](int64_t S) { return pdt_attn_bwd_fuses_dbias((int)S) != 0; });
   bind_reducer(m);
   bind_wordpiece(m);

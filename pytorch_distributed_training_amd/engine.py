@@ -28,6 +28,7 @@ from .data.loader import DeviceLoader, shard_dataloader
 from .ops.arena import ParamArena
 from .optim import FusedAdamW, HFAdamW, LossScaler
 from .parallel.dp import DataParallel
+from .utils.debug import debug_enabled
 
 
 class DistributedType:
@@ -48,7 +49,15 @@ class EngineOptimizer:
         return self.optimizer.param_groups
 
     def step(self, **kw):
+        debug = debug_enabled()
+        if debug:
+            for m in self.engine._models:
+                if isinstance(m, DataParallel) and m.reduction_pending:
+                    raise RuntimeError("optimizer.step() while a gradient reduction is still armed: the last "
+                                       "backward pass did not reach its end-of-backward callback")
         self.optimizer.step(**kw)
+        if debug and self.engine._arena is not None:
+            self.engine._arena.check_guards()
 
     def zero_grad(self, set_to_none: bool = False):
         self.optimizer.zero_grad()

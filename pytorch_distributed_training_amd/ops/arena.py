@@ -89,7 +89,8 @@ def bert_segments(model, prefix: str = "") -> List[Segment]:
 
 class ParamArena:
     def __init__(self, model: nn.Module, device: torch.device, compute_dtype: Optional[torch.dtype] = None,
-                 min_bucket_elems: int = 1 << 20, segments: Optional[List[Segment]] = None):
+                 min_bucket_elems: int = 1 << 20, segments: Optional[List[Segment]] = None,
+                 guard_elems: Optional[int] = None):
         self.model = model
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
@@ -116,10 +117,15 @@ class ParamArena:
             off = _align(off)
             seg.end = off
         self.numel = off
-        f32 = dict(device=self.device, dtype=torch.float32)
-        self.master = torch.zeros(self.numel, **f32)
-        self.grad = torch.zeros(self.numel, **f32)
-        self.p16 = torch.zeros(self.numel, device=self.device, dtype=compute_dtype) if compute_dtype else None
+        if guard_elems is None:
+            from ..utils.debug import guard_elems as _default_guard
+
+            guard_elems = _default_guard()
+        self.guard_elems = int(guard_elems)
+        self._backing: Dict[str, torch.Tensor] = {}
+        self.master = self._alloc("master", torch.float32)
+        self.grad = self._alloc("grad", torch.float32)
+        self.p16 = self._alloc("p16", compute_dtype) if compute_dtype else None
         with torch.no_grad():
             for seg in self.segments:
                 for name, p in seg.params:
@@ -154,6 +160,54 @@ class ParamArena:
             self.sync_compute_copy()
 
     # ------------------------------------------------------------------------------------------
+    _GUARD32, _GUARD16 = 0x7FC0DEAD, 0x7E5A  # NaN patterns: a guard word that leaks into arithmetic is visible
+
+    def _alloc(self, name: str, dtype: torch.dtype) -> torch.Tensor:
+        """Zeroed arena tensor; with guards it is the middle of a larger allocation fenced by sentinel words."""
+        g = self.guard_elems
+        if g == 0:
+            return torch.zeros(self.numel, device=self.device, dtype=dtype)
+        back = torch.zeros(self.numel + 2 * g, device=self.device, dtype=dtype)
+        bits = back.view(torch.int32 if back.element_size() == 4 else torch.int16)
+        pattern = self._GUARD32 if back.element_size() == 4 else self._GUARD16
+        bits[:g].fill_(pattern)
+        bits[g + self.numel:].fill_(pattern)
+        self._backing[name] = back
+        return back[g:g + self.numel]
+
+    def _padding_index(self) -> torch.Tensor:
+        """Element indices of the alignment padding between parameters (never written by anyone)."""
+        if getattr(self, "_pad_idx", None) is None:
+            used = torch.zeros(self.numel, dtype=torch.bool)
+            for o, n in self.offsets.values():
+                used[o:o + n] = True
+            self._pad_idx = (~used).nonzero().flatten().to(self.device)
+        return self._pad_idx
+
+    def check_guards(self) -> None:
+        """Raise :class:`ArenaGuardError` if a guard word changed or alignment padding is non-zero (host sync)."""
+        from ..utils.debug import ArenaGuardError
+
+        g = self.guard_elems
+        for name, back in self._backing.items():
+            bits = back.view(torch.int32 if back.element_size() == 4 else torch.int16)
+            pattern = self._GUARD32 if back.element_size() == 4 else self._GUARD16
+            for side, region in (("below", bits[:g]), ("above", bits[g + self.numel:])):
+                bad = (region != pattern).nonzero().flatten()
+                if bad.numel():
+                    raise ArenaGuardError(f"{name} arena: {bad.numel()} guard words {side} the arena were overwritten "
+                                          f"(first at guard offset {int(bad[0])})")
+        pad = self._padding_index()
+        if pad.numel():
+            for name, t in (("master", self.master), ("grad", self.grad), ("p16", self.p16)):
+                if t is None:
+                    continue
+                bad = (t[pad] != 0).nonzero().flatten()
+                if bad.numel():
+                    e = int(pad[bad[0]])
+                    owner = max((o, n) for n, (o, _) in self.offsets.items() if o <= e)[1]
+                    raise ArenaGuardError(f"{name} arena: alignment padding after '{owner}' is non-zero at element {e}")
+
     def view16(self, name: str, shape: Sequence[int], count: int = 1) -> torch.Tensor:
         """16-bit view starting at parameter `name`, spanning `count` adjacent parameters."""
         o, _ = self.offsets[name]

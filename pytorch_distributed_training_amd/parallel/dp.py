@@ -17,6 +17,8 @@ This is the role torch ``DistributedDataParallel`` plays in the reference
 from __future__ import annotations
 
 import contextlib
+import os
+import time
 from typing import List, Optional
 
 import torch
@@ -117,6 +119,8 @@ class DataParallel(nn.Module):
         self.auto_arm = True  # forward() arms the reducer; a pipeline driver arms it itself before the last backward
         self._armed = False
         self._callback_queued = False
+        self.measure_exposed = os.environ.get("PDT_COMM_TIMING", "0") not in ("", "0")
+        self._exposed: list = []
         runtime = getattr(module, "runtime", None)
         self.native_mode = runtime is not None
         nb = len(arena.bucket_bounds) - 1
@@ -157,7 +161,35 @@ class DataParallel(nn.Module):
         self._callback_queued = False
         if self._armed:
             self._armed = False
-            self.reducer.finish()
+            if not (self.measure_exposed and self.require_sync):
+                self.reducer.finish()
+            elif self.arena.device.type == "cuda":
+                # events on the compute stream around the waits for the collectives: the time the stream
+                # stands still (plus the averaging kernels) is communication that backward did not hide
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.reducer.finish()
+                e1.record()
+                self._exposed.append((e0, e1))
+            else:
+                t0 = time.perf_counter()
+                self.reducer.finish()
+                self._exposed.append((time.perf_counter() - t0) * 1e3)
+
+    @property
+    def reduction_pending(self) -> bool:
+        """True between arming (forward) and the end-of-backward callback."""
+        return self._armed
+
+    def comm_exposed_ms(self) -> Optional[float]:
+        """Mean per-backward milliseconds of gradient communication NOT hidden behind backward since the last
+        call (needs ``measure_exposed``; call it after a host sync, e.g. next to ``loss.item()``)."""
+        if not self._exposed:
+            return None
+        vals = [v if isinstance(v, float) else (v[0].elapsed_time(v[1]) if v[1].query() else None) for v in self._exposed]
+        self._exposed = [v for v, ms in zip(self._exposed, vals) if ms is None]
+        vals = [v for v in vals if v is not None]
+        return sum(vals) / len(vals) if vals else None
 
     def prepare_backward(self) -> None:
         """Arm the reducer for the next backward pass (called from forward)."""

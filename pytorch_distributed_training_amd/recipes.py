@@ -127,6 +127,8 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     logger = StepLogger(engine.is_main_process, cfg.log_every, cfg.log_file,
                         samples_per_step=micro_bs * accum * engine.num_processes)
     dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), engine.process_index)
+    # PDT_COMM_TIMING=1: the log line carries the gradient-communication time that backward did not hide
+    comm_extra = (lambda: {"comm_exposed_ms": model.comm_exposed_ms()}) if getattr(model, "measure_exposed", False) else None
     last_metric: dict = {}
     done = False
     t_start = time.perf_counter()
@@ -155,7 +157,7 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                 global_step += 1
                 dog.heartbeat()
                 inject_fault(engine.process_index, global_step)
-                logger.log_step(global_step, loss * accum, lr_scheduler.get_last_lr()[0], engine.scaler)
+                logger.log_step(global_step, loss * accum, lr_scheduler.get_last_lr()[0], engine.scaler, comm_extra)
                 if cfg.save_every and cfg.output_dir and global_step % cfg.save_every == 0 and engine.is_main_process:
                     ckpt.save_training_state(cfg.output_dir, model, optimizer, lr_scheduler,
                                              {"epoch": epoch, "global_step": global_step})

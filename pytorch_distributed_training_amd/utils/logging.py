@@ -19,7 +19,7 @@ class StepLogger:
         self.samples_per_step, self.tokens_per_step = samples_per_step, tokens_per_step
         self.t_last, self.step_last = time.perf_counter(), 0
 
-    def log_step(self, step: int, loss: torch.Tensor, lr: float, scaler=None, extra: Optional[dict] = None) -> None:
+    def log_step(self, step: int, loss: torch.Tensor, lr: float, scaler=None, extra=None) -> None:
         if not self.is_main or step % self.every:
             return
         now = time.perf_counter()
@@ -32,10 +32,13 @@ class StepLogger:
                 rec["samples_per_s"] = self.samples_per_step * n / dt
         if scaler is not None and scaler.enabled:
             rec["loss_scale"] = scaler.get_scale()
+        if callable(extra):  # evaluated after the loss fetch above, i.e. after the step's host sync
+            extra = extra()
         if extra:
-            rec.update(extra)
+            rec.update({k: v for k, v in extra.items() if v is not None})
         print("step {step}: loss {loss:.4f} lr {lr:.3e}".format(**rec)
-              + (f" {rec['samples_per_s']:.1f} samples/s" if "samples_per_s" in rec else ""), flush=True)
+              + (f" {rec['samples_per_s']:.1f} samples/s" if "samples_per_s" in rec else "")
+              + (f" comm-exposed {rec['comm_exposed_ms']:.2f} ms" if "comm_exposed_ms" in rec else ""), flush=True)
         self._write(rec)
 
     def log_epoch(self, epoch: int, metric: dict) -> None:

@@ -315,3 +315,43 @@ def gpu_single_reference(layout, steps=6):
             if len(losses) >= steps:
                 return losses
     return losses
+
+
+def dp_debug_mode(rank, world):
+    """PDT_DEBUG arena guards + PDT_COMM_TIMING exposed-communication timer through a real DP step."""
+    import os
+
+    os.environ["PDT_DEBUG"] = "1"
+    os.environ["PDT_COMM_TIMING"] = "1"
+    from pytorch_distributed_training_amd.utils.debug import ArenaGuardError
+
+    eng = Engine(cpu=True, min_bucket_mb=0.05)
+    model = _model()
+    opt = AdamW(model.parameters(), lr=1e-3)
+    model, opt = eng.prepare(model, opt)
+    arena = eng.unwrap_model(model).arena
+    assert arena.guard_elems > 0 and model.measure_exposed
+    batch = _global_batch()
+    shard = {k: v[rank::world] for k, v in batch.items()}
+    model.train()
+    for _ in range(2):
+        eng.backward(model(**shard).loss)
+        opt.step()  # runs check_guards()
+        opt.zero_grad()
+    exposed = model.comm_exposed_ms()
+    # armed but never finished: forward without backward, then step
+    model(**shard)
+    armed_error = False
+    try:
+        opt.step()
+    except RuntimeError as e:
+        armed_error = "still armed" in str(e)
+    model.finish_backward()
+    # a stray write below the gradient arena
+    arena._backing["grad"][arena.guard_elems - 1] = 0.0
+    tripped = False
+    try:
+        opt.step()
+    except ArenaGuardError as e:
+        tripped = "grad arena" in str(e)
+    return {"exposed": exposed, "armed_error": armed_error, "tripped": tripped}

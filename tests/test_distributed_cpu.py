@@ -60,3 +60,9 @@ def test_data_parallel_recipe_two_ranks(tmp_path):
     assert res[0]["optimizer_steps"] == res[1]["optimizer_steps"] == 4
     assert res[0]["accuracy"] == res[1]["accuracy"]
     assert os.path.exists(tmp_path / "model.safetensors") and os.path.exists(tmp_path / "training_state.pt")
+
+
+def test_debug_mode_guards_and_exposed_comm_timer():
+    for r in run_distributed(W.dp_debug_mode, 2):
+        assert r["exposed"] is not None and r["exposed"] >= 0.0
+        assert r["armed_error"] and r["tripped"]

@@ -150,6 +150,52 @@ def test_engine_training_reduces_loss_fp16_and_bf16():
         assert last < first - 0.05, (kw, first, last)
 
 
+def test_debug_mode_guards_hold_and_serialized_mode_agrees(monkeypatch):
+    """PDT_DEBUG: no native kernel (wgrad, reductions, optimizer, cast) writes outside its arena slice or into
+    alignment padding.  Serialized mode (device drained after every launch) reproduces the normal run with
+    dropout off up to the summation order of the fp32 atomics (bias-gradient column sums, embedding scatter) -
+    a larger difference would mean the normal mode depends on a race between streams."""
+    from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+    from pytorch_distributed_training_amd.engine import Engine
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.ops import native
+    from pytorch_distributed_training_amd.optim import AdamW
+    from pytorch_distributed_training_amd.utils.debug import set_serialized
+
+    monkeypatch.setenv("PDT_DEBUG", "1")
+
+    def run(serialized):
+        set_serialized(serialized)
+        try:
+            eng = Engine(fp16=True, seed=5)
+            torch.manual_seed(0)
+            model = build_model("bert-tiny", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            opt = AdamW(params=model.parameters(), lr=1e-3)
+            model, opt = eng.prepare(model, opt)
+            assert model.arena.guard_elems > 0
+            batch = fixed_batch(8, 64, model.config.vocab_size, device="cuda", seed=2)
+            model.train()
+            losses = []
+            for _ in range(4):
+                out = model(**batch)
+                eng.backward(out.loss)
+                opt.step()  # check_guards() inside
+                opt.zero_grad()
+                losses.append(out.loss.detach().clone())
+            return torch.stack(losses), model.arena.master.clone()
+        finally:
+            set_serialized(False)
+
+    n0 = native().debug_sync_count()
+    l_ser, w_ser = run(True)
+    assert native().debug_sync_count() > n0 + 40
+    n1 = native().debug_sync_count()
+    l_par, w_par = run(False)
+    assert native().debug_sync_count() == n1
+    torch.testing.assert_close(l_ser, l_par, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(w_ser, w_par, rtol=0, atol=2e-4)  # 4 steps of lr 1e-3: a wrong gradient sign moves 2e-3
+
+
 def test_graphed_step_matches_eager_and_redraws_dropout():
     """A step replayed from a captured hipGraph gives the eager loss curve (dropout off), and with dropout on
     every replay draws new masks although the launch arguments are frozen."""

@@ -346,3 +346,43 @@ def test_default_backend_choice(monkeypatch):
     assert launch.default_backend(torch.device("cuda", 0), env) == "gloo"
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     assert launch.default_backend(torch.device("cuda", 0), env) == "nccl"
+
+
+def test_arena_guards_and_padding_canaries():
+    from pytorch_distributed_training_amd.utils.debug import ArenaGuardError
+
+    torch.manual_seed(0)
+    model = build_model("bert-tiny")
+    plain = ParamArena(build_model("bert-tiny"), torch.device("cpu"))
+    assert plain.guard_elems == 0 and not plain._backing
+    arena = ParamArena(model, torch.device("cpu"), guard_elems=256)
+    assert arena.master.numel() == plain.numel and arena.grad.data_ptr() % 16 == 0
+    arena.check_guards()
+    opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.01)
+    for p in model.parameters():
+        p.grad.normal_()
+    opt.step()
+    arena.check_guards()  # optimizer and weight decay keep guards and padding intact
+    pad = arena._padding_index()
+    assert pad.numel() > 0  # the 2-element classifier bias is padded to the 64-element alignment
+    arena.grad[pad[0]] = 1.0
+    with pytest.raises(ArenaGuardError, match="alignment padding after 'classifier.bias'"):
+        arena.check_guards()
+    arena.grad[pad[0]] = 0.0
+    arena._backing["master"][-1] = 3.0
+    with pytest.raises(ArenaGuardError, match="master arena: 1 guard words above"):
+        arena.check_guards()
+
+
+def test_step_logger_evaluates_lazy_extra(tmp_path, capsys):
+    import json
+
+    from pytorch_distributed_training_amd.utils.logging import StepLogger
+
+    path = tmp_path / "log.jsonl"
+    lg = StepLogger(True, every=1, path=str(path), samples_per_step=8)
+    lg.log_step(1, torch.tensor(0.5), 1e-3, extra=lambda: {"comm_exposed_ms": 1.25, "skipped": None})
+    lg.close()
+    rec = json.loads(path.read_text().strip())
+    assert rec["comm_exposed_ms"] == 1.25 and "skipped" not in rec
+    assert "comm-exposed 1.25 ms" in capsys.readouterr().out
