@@ -41,9 +41,12 @@ typedef struct PdtGemm {
   PdtRng rng;
   int k_per_split;
   int tiles_m, tiles_n, splits;
-  // optional fp32 [N]: column sums of the stored C (the bias gradient of the layer that produced C's input)
-  // are added here with fp32 atomics, one add per column per 32-row slab of a wave
+  // optional fp32 [2 * ceil(M / 128)][N] partial column sums of the stored C (the bias gradient of the layer
+  // that produced C's input): every wave row of every tile row stores the sums of its rows into a row of its
+  // own (plain stores, no atomics, deterministic); the launcher reports in colsum_rows how many rows were
+  // written (2 per tile row), and pdt_colsum_finish() adds them up.
   float* colsum;
+  int colsum_rows;
   // optional fp32 workspace [ws_splits][M][N] for split-K forward / dgrad GEMMs: when non-null (and the epilogue
   // has no column sums) the K range is cut into ws_splits slices whose fp32 partial tiles are summed by a
   // second kernel that also applies the epilogue.  pdt_gemm_splits() says how many slices a shape wants.

@@ -165,17 +165,22 @@ struct GemmKernel {
     if (g.colsum) unpack8<T>(packed, v);  // column sums are taken over exactly what was stored
   }
 
-  // add the 8 per-column partial sums a lane collected (over the rows it handled) to g.colsum: first combine
-  // the 8 lanes that share a column block (lane>>3 = row inside a pass), then one lane issues the atomics
-  static __device__ __forceinline__ void flush_colsum(const GemmArgs& g, int n, bool n_ok, float (&cs)[8], int lane) {
+  // store the 8 per-column partial sums a lane collected (over the rows it handled) into row `prow` of the
+  // partial-sum matrix g.colsum: the 8 lanes that share a column block (lane>>3 = row inside a pass) are
+  // combined first, then one of them stores 32 bytes
+  static __device__ __forceinline__ void flush_colsum(const GemmArgs& g, int prow, int n, bool n_ok, float (&cs)[8], int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float v = cs[i];
       v += __shfl_xor(v, 8, 64);
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if ((lane >> 3) == 0 && n_ok) atomicAdd(g.colsum + n + i, v);
-      cs[i] = 0.f;
+      cs[i] = v;
+    }
+    if ((lane >> 3) == 0 && n_ok) {
+      float* dst = g.colsum + (size_t)prow * g.N + n;
+      *reinterpret_cast<float4v*>(dst) = float4v{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<float4v*>(dst + 4) = float4v{cs[4], cs[5], cs[6], cs[7]};
     }
   }
 
@@ -185,10 +190,11 @@ struct GemmKernel {
   // column block lane&7); `n` is the first of the lane's 8 global columns (the same for every row) and
   // mbase(ip) the global row of staged row 0.  The side inputs (aux / res) of row-block pair ip+1 are fetched
   // before pair ip is processed, so their latency hides under the math and the LDS transpose; the bias is
-  // read once; the column sums are kept in registers over the whole wave tile and flushed once.
+  // read once; the column sums are kept in registers over the whole wave tile and stored once, into row `prow`
+  // (tile row * 2 + wave row) of the partial-sum matrix.
   template <int NIP, int epi, typename MBase>
   static __device__ __forceinline__ void staged_epilogue_as(const GemmArgs& g, float4v (&acc)[2 * NIP][4], char* stg, int n,
-                                                            MBase mbase, int lane) {
+                                                            MBase mbase, int prow, int lane) {
     const int lm = lane & 15, lg = lane >> 4, jc = lane & 7, rsub = lane >> 3;
     const bool n_ok = n < g.N;
     const DropKey dk = drop_key(g.rng);
@@ -239,7 +245,7 @@ struct GemmKernel {
         }
       }
     }
-    if (g.colsum) flush_colsum(g, n, n_ok, cs, lane);
+    if (g.colsum) flush_colsum(g, prow, n, n_ok, cs, lane);
   }
 
   // The epilogue kind is a run-time argument of the kernel but a compile-time parameter of the (fully unrolled)
@@ -255,23 +261,23 @@ struct GemmKernel {
   }
   template <int NIP, typename MBase>
   static __device__ __forceinline__ void staged_epilogue(const GemmArgs& g, float4v (&acc)[2 * NIP][4], char* stg, int n,
-                                                         MBase mbase, int lane) {
+                                                         MBase mbase, int prow, int lane) {
     if (!AKS && !BKS) {
       switch (g.epi) {
-        case EPI_BIAS: return staged_epilogue_as<NIP, EPI_BIAS>(g, acc, stg, n, mbase, lane);
-        case EPI_BIAS_GELU: return staged_epilogue_as<NIP, EPI_BIAS_GELU>(g, acc, stg, n, mbase, lane);
-        case EPI_BIAS_DROP_RES: return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES>(g, acc, stg, n, mbase, lane);
-        case EPI_BIAS_TANH: return staged_epilogue_as<NIP, EPI_BIAS_TANH>(g, acc, stg, n, mbase, lane);
+        case EPI_BIAS: return staged_epilogue_as<NIP, EPI_BIAS>(g, acc, stg, n, mbase, prow, lane);
+        case EPI_BIAS_GELU: return staged_epilogue_as<NIP, EPI_BIAS_GELU>(g, acc, stg, n, mbase, prow, lane);
+        case EPI_BIAS_DROP_RES: return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES>(g, acc, stg, n, mbase, prow, lane);
+        case EPI_BIAS_TANH: return staged_epilogue_as<NIP, EPI_BIAS_TANH>(g, acc, stg, n, mbase, prow, lane);
         default: break;
       }
     } else if (!AKS && BKS) {
       switch (g.epi) {
-        case EPI_MUL_DGELU: return staged_epilogue_as<NIP, EPI_MUL_DGELU>(g, acc, stg, n, mbase, lane);
-        case EPI_ADD_RES: return staged_epilogue_as<NIP, EPI_ADD_RES>(g, acc, stg, n, mbase, lane);
+        case EPI_MUL_DGELU: return staged_epilogue_as<NIP, EPI_MUL_DGELU>(g, acc, stg, n, mbase, prow, lane);
+        case EPI_ADD_RES: return staged_epilogue_as<NIP, EPI_ADD_RES>(g, acc, stg, n, mbase, prow, lane);
         default: break;
       }
     }
-    staged_epilogue_as<NIP, EPI_PLAIN>(g, acc, stg, n, mbase, lane);
+    staged_epilogue_as<NIP, EPI_PLAIN>(g, acc, stg, n, mbase, prow, lane);
   }
 
   static __device__ __forceinline__ void run(const GemmArgs& g) {
@@ -353,9 +359,9 @@ struct GemmKernel {
       }
       return;
     }
-    static_assert(FN == 4 && FM % 2 == 0, "staged epilogue shape");
+    static_assert(FN == 4 && FM % 2 == 0 && WAVES_M == 2, "staged epilogue shape (2 partial column-sum rows per tile row)");
     staged_epilogue<FM / 2>(g, acc, smem + wave * (32 * 256), n0 + wn * WTN + (lane & 7) * 8,
-                            [&](int ip) { return m0 + wm * WTM + ip * 32; }, lane);
+                            [&](int ip) { return m0 + wm * WTM + ip * 32; }, tm * WAVES_M + wm, lane);
   }
 };
 

@@ -257,7 +257,7 @@ struct Gemm8 {
     // m-half ip>>1, rows (ip&1)*32.. of the wave's 64
     Base::template staged_epilogue<4>(g, acc, smem + wave * (32 * 256),
                                       n0 + ((lane & 7) >> 2) * 128 + wc * 32 + (lane & 3) * 8,
-                                      [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, lane);
+                                      [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, tm * 2 + wr, lane);
   }
 };
 

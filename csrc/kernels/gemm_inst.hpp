@@ -81,6 +81,7 @@ static int launch_tile(PdtGemm& g, hipStream_t stream) {
   }
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
+  g.colsum_rows = 2 * g.tiles_m;
   auto launch = [&](PdtGemm& gg) {
     const int grid = gg.tiles_m * gg.tiles_n * gg.splits;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, stream, gg);
@@ -106,6 +107,7 @@ static int launch_pingpong(PdtGemm& g, hipStream_t stream) {
   }
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
+  g.colsum_rows = 2 * g.tiles_m;
   if (g.epi != PDT_EPI_SLAB_F32) {
     g.splits = 1;
     g.k_per_split = ((g.K + 63) / 64) * 64;

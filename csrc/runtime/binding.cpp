@@ -130,7 +130,8 @@ struct Epi {
   Tensor* aux = nullptr;
   double drop_p = 0.0;
   PdtRng rng{nullptr, 0, 0};
-  float* colsum = nullptr;  // fp32 [N]: += column sums of the stored output (a bias gradient)
+  Tensor* colsum = nullptr;  // fp32 [N]: (+)= column sums of the stored output (a bias gradient)
+  bool colsum_accumulate = true;
 };
 
 void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, int N, int K, const Epi& e, int tile = -1) {
@@ -145,7 +146,14 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
   g.drop_thr = thr16(e.drop_p);
   g.drop_scale = keep_scale(e.drop_p);
   g.rng = e.rng;
-  g.colsum = e.colsum;
+  // column sums: the kernel stores per-wave-row partial sums, a finishing kernel adds them up
+  Tensor cs_part;
+  if (e.colsum) {
+    chkf32(*e.colsum, "colsum");
+    TORCH_CHECK(e.colsum->numel() == N, "colsum must have N elements");
+    cs_part = at::empty({2 * (((int64_t)M + 127) / 128), (int64_t)N}, C.options().dtype(at::kFloat));
+    g.colsum = cs_part.data_ptr<float>();
+  }
   // few output tiles + long K: split K over fp32 partial slabs, summed by the epilogue kernel
   Tensor ws;
   const int splits = pdt_gemm_splits(layout, tile, &g);
@@ -155,6 +163,9 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
     g.ws_splits = splits;
   }
   check(pdt_gemm(dt_code(A), layout, tile, &g, cur_stream()), "gemm");
+  if (e.colsum)
+    check(pdt_colsum_finish(cs_part.data_ptr<float>(), g.colsum_rows, N, 1, e.colsum->data_ptr<float>(), nullptr, nullptr,
+                            nullptr, e.colsum_accumulate ? 1 : 0, cur_stream()), "colsum_finish");
 }
 
 // C[M,N] = A[M,K] * W[N,K]^T (+ epilogue)
@@ -296,9 +307,9 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
   LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2),
                        accumulate);
-  // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU, fp32 atomics) ; wgrad
-  if (!accumulate) gr[7].zero_();
-  Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u); e_dg.colsum = gr[7].data_ptr<float>();
+  // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU) ; wgrad
+  Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
+  e_dg.colsum = &gr[7]; e_dg.colsum_accumulate = accumulate;
   WgradLane lane(g_wgrad_mode == 2 || (g_wgrad_mode == 1 && T <= kWgradLaneMaxTokens));
   lane.run([&] { gemm_tn_into(l2.ddrop, gact, gr[8], accumulate); });
   Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
@@ -507,7 +518,7 @@ Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int6
                c10::optional<Tensor> colsum) {
   DeviceGuard guard(A.device());
   Epi e; e.kind = (int)epi; e.drop_p = drop_p;
-  if (colsum.has_value()) { chkf32(*colsum, "colsum"); e.colsum = colsum->data_ptr<float>(); }
+  if (colsum.has_value()) e.colsum = &*colsum;  // adds to the tensor's content
   if (bias.has_value()) e.bias = &*bias;
   if (res.has_value()) e.res = &*res;
   if (aux.has_value()) e.aux = &*aux;

@@ -124,6 +124,10 @@ def test_gemm_nn_dgrad(dtype, tile, M, N, K):
     rt, at = tol(dtype)
     torch.testing.assert_close(out2.float(), out.float(), rtol=rt, atol=at)
     torch.testing.assert_close(cs, 1 + out2.float().sum(0), rtol=2e-3, atol=2e-2)
+    # the sums are formed without atomics: a second run is bit-identical
+    cs2 = torch.ones(N, device="cuda")
+    C().op_gemm("nn", dY, W, 4, None, None, u, None, 0.0, 0, 0, tile, cs2)
+    assert torch.equal(cs, cs2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
