@@ -75,7 +75,7 @@ def main():
             "add_res": lambda: C.op_gemm("nn", g, w1, 5, None, x, None, None, 0.0, 0, 0, -1),
         }),
     }
-    C.op_gemm("nt", x, w1, 2, b1, None, z1, None, 0.0, 0, 0, -1)  # fill z1 with real pre-activations
+    C.op_gemm("nt", x, w1, 2, b1, None, z1, None, 0.0, 0, 0, -1)  # fill z1 with real GELU derivatives
     for name, (fl, cands) in groups.items():
         for f in cands.values():
             f()

@@ -149,24 +149,6 @@ __device__ __forceinline__ uint32_t drop_keep8(const DropKey& k, uint64_t g, uin
 // below 16-bit output rounding): one v_exp_f32 + one v_rcp_f32 + a 5-term Horner chain.  With x = u/sqrt(2) the
 // exponential exp(-x^2) = exp(-u^2/2) is also the Gaussian of the derivative, so gelu and gelu' share it.
 // The GEMM epilogues call this once per output element; the libm erff costs ~3x more VALU work there.
-struct GeluParts {
-  float cdf;  // Phi(u) = 0.5 * (1 + erf(u / sqrt(2)))
-  float pdf;  // phi(u) = exp(-u^2 / 2) / sqrt(2 pi)
-};
-__device__ __forceinline__ GeluParts gelu_parts(float u) {
-  const float x = fabsf(u) * 0.70710678118654752f;
-  const float e = __expf(-x * x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float p = fmaf(t, 1.061405429f, -1.453152027f);
-  p = fmaf(t, p, 1.421413741f);
-  p = fmaf(t, p, -0.284496736f);
-  p = fmaf(t, p, 0.254829592f);
-  const float half_erfc = 0.5f * p * t * e;  // 0.5 * erfc(|x|)
-  GeluParts r;
-  r.cdf = u >= 0.f ? 1.0f - half_erfc : half_erfc;
-  r.pdf = 0.3989422804014327f * e;
-  return r;
-}
 // Two elements at a time on <2 x float>: the multiply/add chain becomes packed fp32 instructions
 // (v_pk_mul_f32 / v_pk_fma_f32, two lanes' worth of math per issue); exp and rcp stay scalar.
 __device__ __forceinline__ void gelu_parts2(float2v u, float2v& cdf, float2v& pdf) {
@@ -183,33 +165,20 @@ __device__ __forceinline__ void gelu_parts2(float2v u, float2v& cdf, float2v& pd
   cdf = float2v{u.x >= 0.f ? 1.0f - h.x : h.x, u.y >= 0.f ? 1.0f - h.y : h.y};
   pdf = e * 0.3989422804014327f;
 }
-// v[i] = gelu(v[i]) / v[i] *= gelu'(u[i]) on 8 values (the unit of the GEMM epilogues)
-__device__ __forceinline__ void gelu8(float (&v)[8]) {
+// v[i] = gelu(v[i]) and d[i] = gelu'(v[i]) on 8 values (the unit of the GEMM epilogues): the forward epilogue has
+// cdf and pdf in registers anyway, so it emits the derivative for the backward pass at the cost of one packed fma
+__device__ __forceinline__ void gelu8(float (&v)[8], float (&d)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
-    float2v c, d;
+    float2v c, p;
     const float2v u = float2v{v[i], v[i + 1]};
-    gelu_parts2(u, c, d);
+    gelu_parts2(u, c, p);
     const float2v r = u * c;
+    const float2v g = u * p + c;
     v[i] = r.x; v[i + 1] = r.y;
+    d[i] = g.x; d[i + 1] = g.y;
   }
 }
-__device__ __forceinline__ void mul_gelu_grad8(float (&v)[8], const float (&u8)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    float2v c, d;
-    const float2v u = float2v{u8[i], u8[i + 1]};
-    gelu_parts2(u, c, d);
-    const float2v r = float2v{v[i], v[i + 1]} * (u * d + c);
-    v[i] = r.x; v[i + 1] = r.y;
-  }
-}
-__device__ __forceinline__ float gelu_f(float u) { return u * gelu_parts(u).cdf; }
-__device__ __forceinline__ float gelu_grad_f(float u) {
-  const GeluParts g = gelu_parts(u);
-  return fmaf(u, g.pdf, g.cdf);
-}
-
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (and its
 // L2), so give each XCD a contiguous run of tiles.  Pure speed lever, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -19,9 +19,9 @@ namespace pdt {
 enum GemmEpilogue : int {
   EPI_PLAIN = PDT_EPI_PLAIN,                  // C = acc
   EPI_BIAS = PDT_EPI_BIAS,                    // C = acc + bias[n]
-  EPI_BIAS_GELU = PDT_EPI_BIAS_GELU,          // aux = acc + bias[n] ; C = gelu(aux)
+  EPI_BIAS_GELU = PDT_EPI_BIAS_GELU,          // u = acc + bias[n] ; C = gelu(u) ; aux = gelu'(u)
   EPI_BIAS_DROP_RES = PDT_EPI_BIAS_DROP_RES,  // C = dropout(acc + bias[n]) + res[m,n]
-  EPI_MUL_DGELU = PDT_EPI_MUL_DGELU,          // C = acc * gelu'(aux[m,n])
+  EPI_MUL_DGELU = PDT_EPI_MUL_DGELU,          // C = acc * aux[m,n]   (aux = gelu'(u) saved by BIAS_GELU)
   EPI_ADD_RES = PDT_EPI_ADD_RES,              // C = acc + res[m,n]
   EPI_SLAB_F32 = PDT_EPI_SLAB_F32,            // split-K partial: fp32 slab[split][m,n] = acc
   EPI_BIAS_TANH = PDT_EPI_BIAS_TANH,          // C = tanh(acc + bias[n])
@@ -138,16 +138,19 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] += bias[i];
     }
     if (epi == EPI_BIAS_GELU) {
-      // the pre-activation is not read again before the backward pass: keep it out of the caches
-      __builtin_nontemporal_store(pack8<T>(v), reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n));
-      gelu8(v);
+      // aux = gelu'(pre-activation): all the backward pass needs of it (MUL_DGELU is then a plain multiply, no
+      // exp / rcp in the data-gradient epilogue).  Not read again before backward: keep it out of the caches.
+      float d[8];
+      gelu8(v, d);
+      __builtin_nontemporal_store(pack8<T>(d), reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n));
     } else if (epi == EPI_BIAS_TANH) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
     } else if (epi == EPI_MUL_DGELU) {
-      float u[8];
-      unpack8<T>(ext, u);
-      mul_gelu_grad8(v, u);
+      float d[8];
+      unpack8<T>(ext, d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= d[i];
     }
     if (epi == EPI_BIAS_DROP_RES && g.drop_thr != 0) {
       const uint32_t keep = drop_keep8(dk, ((uint64_t)m * g.N + n) >> 3, g.drop_thr);

@@ -279,7 +279,7 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
   Tensor stats1 = at::empty({T, 2}, f32);
   Tensor x1 = ln_fwd(z1, w[4], w[5], stats1, eps);
 
-  Tensor u = at::empty({T, (int64_t)w[6].size(0)}, x.options());
+  Tensor u = at::empty({T, (int64_t)w[6].size(0)}, x.options());  // gelu'(FFN1 pre-activation), for backward
   Epi e_f1; e_f1.kind = PDT_EPI_BIAS_GELU; e_f1.bias = &w[7]; e_f1.aux = &u;
   Tensor gact = gemm_nt(x1, w[6], e_f1);
 
