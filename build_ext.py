@@ -69,12 +69,19 @@ def _compile(src, obj, cmd, stamp, verbose):
     return src, time.time() - t0, False
 
 
-def build(jobs: int = 8, verbose: bool = False, force: bool = False) -> str:
+def build(jobs: int = 8, verbose: bool = False, force: bool = False, kernel_defines=(), variant: str = "") -> str:
+    """Build the extension.  ``variant`` + ``kernel_defines`` (``-D`` macros of the kernel sources, e.g.
+    ``PDT_PHASES=4``) build an A/B copy ``_C_<variant>.so`` next to ``_C.so`` with its own object cache;
+    ``PDT_NATIVE_LIB=<path>`` makes the package load it instead of the default build."""
+    global BUILD, OUT
+    if variant:
+        BUILD, OUT = os.path.join(ROOT, "build", "variant_" + variant), os.path.join(PKG, f"_C_{variant}.so")
     os.makedirs(BUILD, exist_ok=True)
     inc, tlib, abi = _torch_paths()
     hip, cpp, hdr = _sources()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     dev_flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    dev_flags += [f"-D{d}" for d in kernel_defines]
     host_flags = ["-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
                   "-DTORCH_EXTENSION_NAME=_C", "-DTORCH_API_INCLUDE_EXTENSION_H",
                   f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-Wno-deprecated-declarations"] + [f"-I{p}" for p in inc]
@@ -115,5 +122,9 @@ if __name__ == "__main__":
     ap.add_argument("-j", "--jobs", type=int, default=min(8, os.cpu_count() or 8))
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="macro for the kernel sources (A/B builds)")
+    ap.add_argument("--variant", default="", help="build _C_<variant>.so instead of _C.so")
     a = ap.parse_args()
-    build(a.jobs, a.verbose, a.force)
+    if a.defines and not a.variant:
+        ap.error("-D needs --variant: the default build always uses the defaults in the sources")
+    build(a.jobs, a.verbose, a.force, a.defines, a.variant)

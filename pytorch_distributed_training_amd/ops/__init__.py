@@ -7,6 +7,7 @@ missing instead of silently falling back to eager PyTorch.
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import os
 
 _C = None
@@ -20,7 +21,14 @@ def _load():
     try:
         import torch  # noqa: F401  (loads the HIP runtime the extension links against)
 
-        _C = importlib.import_module("pytorch_distributed_training_amd._C")
+        alt = os.environ.get("PDT_NATIVE_LIB")
+        if alt:  # an A/B build made with `build_ext.py --variant`
+            spec = importlib.util.spec_from_file_location("pytorch_distributed_training_amd._C", alt)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _C = mod
+        else:
+            _C = importlib.import_module("pytorch_distributed_training_amd._C")
     except Exception as e:  # pragma: no cover - depends on the build
         _ERR = e
 
