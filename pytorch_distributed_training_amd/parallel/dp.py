@@ -137,10 +137,29 @@ class DataParallel(nn.Module):
                         p.register_post_accumulate_grad_hook(self._make_hook(seg.bucket))
             expected = [max(1, e) for e in expected]
         self.reducer = make_reducer(self.pg, arena, expected, True, comm_dtype)
+        if self.world_size > 1:
+            self._verify_replicas()
         if broadcast_from is not None and self.world_size > 1:
             # rank-0 parameters to everyone (what DDP's constructor does), then refresh the 16-bit copy
             self.reducer.broadcast(arena.master, broadcast_from)
             arena.sync_compute_copy()
+
+    def _verify_replicas(self) -> None:
+        """Every rank must hold the same parameters in the same arena layout (torch DDP's constructor verifies
+        parameter shapes across ranks the same way); a mismatch would otherwise surface as a hang or as silently
+        mixed-up gradients in the first all-reduce."""
+        import zlib
+
+        layout = ";".join(f"{n}:{o}:{k}" for n, (o, k) in sorted(self.arena.offsets.items()))
+        mine = torch.tensor([self.arena.numel, len(self.arena.offsets), len(self.arena.bucket_bounds) - 1,
+                             zlib.crc32(layout.encode())], dtype=torch.int64, device=self.arena.device)
+        every = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(every, mine, group=self.pg)
+        bad = [r for r, t in enumerate(every) if not torch.equal(t, every[0])]
+        if bad:
+            raise RuntimeError(f"data-parallel replicas differ: ranks {bad} do not match rank 0 "
+                               f"(arena elements / parameters / buckets / layout hash: "
+                               f"{[t.tolist() for t in every]})")
 
     # -- reducer plumbing ----------------------------------------------------------------------------
     def _make_hook(self, bucket: int):

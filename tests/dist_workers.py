@@ -355,3 +355,15 @@ def dp_debug_mode(rank, world):
     except ArenaGuardError as e:
         tripped = "grad arena" in str(e)
     return {"exposed": exposed, "armed_error": armed_error, "tripped": tripped}
+
+
+def dp_replica_mismatch(rank, world):
+    """Rank 1 builds a 3-label head: the DataParallel constructor must refuse on every rank."""
+    eng = Engine(cpu=True, min_bucket_mb=0.05)
+    torch.manual_seed(0)
+    model = build_model("bert-tiny", num_labels=2 if rank == 0 else 3)
+    try:
+        eng.prepare(model)
+    except RuntimeError as e:
+        return "replicas differ" in str(e) and "[1]" in str(e)
+    return False

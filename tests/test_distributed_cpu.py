@@ -66,3 +66,7 @@ def test_debug_mode_guards_and_exposed_comm_timer():
     for r in run_distributed(W.dp_debug_mode, 2):
         assert r["exposed"] is not None and r["exposed"] >= 0.0
         assert r["armed_error"] and r["tripped"]
+
+
+def test_replica_layout_is_verified_across_ranks():
+    assert all(run_distributed(W.dp_replica_mismatch, 2))
