@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from .dp import DataParallel
 from .groups import ParallelMesh
+from ..utils.profile import trace_range
 
 
 def split_layers(num_layers: int, stages: int) -> List[Tuple[int, int]]:
@@ -111,14 +112,17 @@ class PipelineStage:
         return torch.empty(b, s, self.hidden, dtype=self.act_dtype, device=self.engine.device)
 
     def _send(self, t: torch.Tensor, dst: int) -> None:
-        _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)])
+        with trace_range("pp.send"):
+            _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)])
 
     def _recv(self, buf: torch.Tensor, src: int) -> torch.Tensor:
-        _p2p([dist.P2POp(dist.irecv, buf, src)])
+        with trace_range("pp.recv"):
+            _p2p([dist.P2POp(dist.irecv, buf, src)])
         return buf
 
     def _send_recv(self, t: torch.Tensor, buf: torch.Tensor, peer: int) -> torch.Tensor:
-        _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)])
+        with trace_range("pp.send_recv"):
+            _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)])
         return buf
 
     def _arm(self) -> None:

@@ -40,6 +40,7 @@ from .models.bert import build_model
 from .models.config import preset
 from .optim import AdamW, get_linear_schedule_with_warmup
 from .utils.logging import StepLogger
+from .utils.profile import trace_range
 from .utils.seed import set_seed
 from .utils.watchdog import StepWatchdog, inject_fault
 
@@ -145,14 +146,18 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                 pending += 1
                 fire = pending == accum or step == micro_per_epoch - 1
                 sync_ctx = _Null() if fire else engine.no_sync(model)
+            logger.add_tokens(batch["input_ids"].numel() * engine.num_processes)
             with sync_ctx:
-                outputs = model(**batch)
-                loss = outputs.loss / accum
-                engine.backward(loss)
+                with trace_range("forward"):
+                    outputs = model(**batch)
+                    loss = outputs.loss / accum
+                with trace_range("backward+reduce" if fire else "backward"):
+                    engine.backward(loss)
             if fire:
-                optimizer.step()
-                lr_scheduler.step()
-                optimizer.zero_grad()
+                with trace_range("optimizer"):
+                    optimizer.step()
+                    lr_scheduler.step()
+                    optimizer.zero_grad()
                 pending = 0
                 global_step += 1
                 dog.heartbeat()

@@ -18,9 +18,17 @@ class StepLogger:
         self.file = open(path, "a") if (path and is_main) else None
         self.samples_per_step, self.tokens_per_step = samples_per_step, tokens_per_step
         self.t_last, self.step_last = time.perf_counter(), 0
+        self._tokens = 0
+
+    def add_tokens(self, n: int) -> None:
+        """Count `n` (padded) tokens processed by the whole job since the last log line; with dynamic padding
+        the per-step token count varies, so the training loop reports it per micro-batch."""
+        self._tokens += int(n)
 
     def log_step(self, step: int, loss: torch.Tensor, lr: float, scaler=None, extra=None) -> None:
-        if not self.is_main or step % self.every:
+        if not self.is_main:
+            return
+        if step % self.every:
             return
         now = time.perf_counter()
         dt, n = now - self.t_last, step - self.step_last
@@ -30,6 +38,10 @@ class StepLogger:
             rec["steps_per_s"] = n / dt
             if self.samples_per_step:
                 rec["samples_per_s"] = self.samples_per_step * n / dt
+            tokens = self._tokens or self.tokens_per_step * n
+            if tokens:
+                rec["tokens_per_s"] = tokens / dt
+        self._tokens = 0
         if scaler is not None and scaler.enabled:
             rec["loss_scale"] = scaler.get_scale()
         if callable(extra):  # evaluated after the loss fetch above, i.e. after the step's host sync
