@@ -16,7 +16,9 @@ def _load_roctx():
     global _roctx
     if _roctx is None:
         _roctx = False
-        for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+        # rocprofv3 (--marker-trace) records the rocprofiler-sdk flavour of roctx; the roctracer one is the fallback
+        for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so",
+                     "/opt/rocm/lib/libroctx64.so"):
             try:
                 lib = ctypes.CDLL(name)
                 lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
