@@ -39,8 +39,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="bert-large-cased")
     ap.add_argument("--seq-len", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=256,
-                    help="per-GPU samples per optimizer step (sized for 288 GB HBM, not for the reference's 8-sample micro-batches)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU samples per optimizer step; default 131072 tokens / seq_len (1024 at seq 128: ~105 GB of "
+                         "activations, sized for 288 GB HBM, not for the reference's 8-sample micro-batches)")
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
@@ -50,6 +51,8 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = max(1, 131072 // args.seq_len)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -149,6 +152,7 @@ def main() -> None:
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
                        "hip_graph": bool(args.graph),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,
                        "optimizer": "fused AdamW + dynamic loss scale",
                        "dropout": 0.1},
         }))

@@ -97,7 +97,7 @@ class _LayerFn(torch.autograd.Function):
             B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
             micro, layer.index + nat.site_offset, acc)
-        ctx.saved = None
+        ctx.saved = ctx.x2 = None
         nat.rt.done(nat.segment)
         return dx.view(B, S, H), None, None
 
@@ -186,15 +186,18 @@ class _DenseTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, nat):
         out = native().dense_tanh_forward(first, nat.w, nat.b)
-        ctx.nat, ctx.first, ctx.out = nat, first, out
+        ctx.nat = nat
+        # an OUTPUT kept as a plain ctx attribute would close a reference cycle (ctx -> out -> grad_fn -> ctx)
+        # that keeps the whole graph and its activations alive until the cycle collector runs
+        ctx.save_for_backward(first, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         nat: DenseNative = ctx.nat
-        out = ctx.out
+        first, out = ctx.saved_tensors
         dpre = (dout.float() * (1.0 - out.float() ** 2)).to(out.dtype)
-        dfirst = native().dense_backward(dpre.contiguous(), ctx.first, nat.w, nat.gw, nat.gb, True)
+        dfirst = native().dense_backward(dpre.contiguous(), first, nat.w, nat.gw, nat.gb, True)
         nat.rt.done(nat.segment)  # the dense layer is the last producer of the head segment in backward order
         return dfirst, None
 
@@ -220,7 +223,8 @@ class _HeadFn(torch.autograd.Function):
     def forward(ctx, pooled, nat, labels, p, site):
         micro = nat.rt.micro
         logits, loss = native().head_forward(pooled, nat.w, nat.b, labels, nat.rt.rng_state, p, micro, site)
-        ctx.nat, ctx.pooled, ctx.logits, ctx.labels = nat, pooled, logits, labels
+        ctx.nat, ctx.has_labels = nat, labels is not None
+        ctx.save_for_backward(pooled, logits, *([labels] if labels is not None else []))  # logits is an output
         ctx.meta = (p, micro, site)
         ctx.set_materialize_grads(False)  # an unused output arrives as None instead of a zero tensor
         return logits, loss
@@ -229,8 +233,10 @@ class _HeadFn(torch.autograd.Function):
     def backward(ctx, dlogits, dloss):
         nat: HeadNative = ctx.nat
         p, micro, site = ctx.meta
-        dp = native().head_backward(dloss if ctx.labels is not None else None, dlogits, ctx.pooled, nat.w, ctx.logits,
-                                    ctx.labels, nat.gw, nat.gb, nat.rt.rng_state, p, micro, site, True, False)
+        pooled, logits = ctx.saved_tensors[:2]
+        labels = ctx.saved_tensors[2] if ctx.has_labels else None
+        dp = native().head_backward(dloss if labels is not None else None, dlogits, pooled, nat.w, logits,
+                                    labels, nat.gw, nat.gb, nat.rt.rng_state, p, micro, site, True, False)
         return dp, None, None, None, None
 
 

@@ -481,3 +481,67 @@ def test_gelu_epilogue_matches_erf_gelu_closely():
     bf = b.float().requires_grad_()
     F.gelu(bf).sum().backward()
     assert (d[0].float() - bf.grad).abs().max().item() <= 2e-3
+
+
+# ------------------------------------------------------------------------------ large token counts
+def test_kernels_at_131072_tokens():
+    """Per-GPU batch 1024 x 128 tokens (what the 288 GB of HBM are sized for): every index computation of the
+    hot kernels at offsets beyond 2^30 bytes - checked on the last rows / samples against fp32 PyTorch."""
+    torch.manual_seed(12)
+    dtype = torch.float16
+    T, H, F4, S, A = 131072, 1024, 4096, 128, 16
+    B = T // S
+    tail = slice(T - 300, T)
+    mid = slice(T // 2 + 5, T // 2 + 133)
+    x = (torch.randn(T, H, device="cuda") * 0.5).to(dtype)
+    w1 = (torch.randn(F4, H, device="cuda") * 0.05).to(dtype)
+    b1 = torch.randn(F4, device="cuda").to(dtype)
+    aux = torch.empty(T, F4, device="cuda", dtype=dtype)
+    act = C().op_gemm("nt", x, w1, 2, b1, None, aux, None, 0.0, 0, 0, -1)
+    for rows in (tail, mid):
+        pre = x[rows].float() @ w1.float().t() + b1.float()
+        assert rel_err(act[rows], F.gelu(pre)) < 5e-3
+        assert rel_err(aux[rows], gelu_grad(pre)) < 5e-3
+    # data gradient with the saved derivative (NN, 4096-wide output) and with a residual (NN, 1024-wide output)
+    w2 = (torch.randn(H, F4, device="cuda") * 0.05).to(dtype)  # [out=H, in=4H]
+    du = C().op_gemm("nn", x, w2, 4, None, None, aux, None, 0.0, 0, 0, -1)
+    for rows in (tail, mid):
+        assert rel_err(du[rows], (x[rows].float() @ w2.float()) * aux[rows].float()) < 5e-3
+    dx = C().op_gemm("nn", act, w1, 5, None, x, None, None, 0.0, 0, 0, -1)
+    for rows in (tail, mid):
+        assert rel_err(dx[rows], act[rows].float() @ w1.float() + x[rows].float()) < 5e-3
+    # weight gradient: K = 131072 rows
+    G = C().op_gemm_tn(act, x, None, False, -1, 0)
+    ref = torch.zeros(F4, H, device="cuda")
+    for c in range(0, T, 16384):
+        ref += act[c:c + 16384].float().t() @ x[c:c + 16384].float()
+    assert rel_err(G, ref) < 3e-3
+    # LayerNorm forward / backward on the last rows
+    g, b = torch.randn(H, device="cuda").to(dtype), torch.randn(H, device="cuda").to(dtype)
+    y, stats = C().op_layernorm_fwd(x, g, b, 1e-12)
+    xr = x[tail].float().requires_grad_()
+    yr = F.layer_norm(xr, (H,), g.float(), b.float(), 1e-12)
+    assert rel_err(y[tail], yr) < 5e-3
+    dy = (torch.randn(T, H, device="cuda") * 0.5).to(dtype)
+    dxl = C().op_layernorm_bwd(dy, x, stats, g, None, 0.0, 0, 0)[0]
+    yr.backward(dy[tail].float())
+    assert rel_err(dxl[tail], xr.grad) < 5e-3
+    del act, aux, du, dx, y, dxl
+    # attention on the last samples of 1024
+    qkv = (torch.randn(T, 3 * H, device="cuda") * 0.5).to(dtype)
+    mask = torch.ones(B, S, device="cuda", dtype=torch.int32)
+    mask[-1, 100:] = 0
+    kv_len = mask.sum(1).to(torch.int32)
+    ctx, lse = C().op_attn_fwd(qkv, mask, kv_len, B, S, A, None, 0.0, 0, 0)
+    nb = 3
+    qf = qkv[-nb * S:].float().requires_grad_()
+    cref, _ = ref_attention(qf, mask[-nb:], nb, S, A)
+    vm = mask[-nb:].reshape(nb * S, 1).float()
+    assert rel_err(ctx[-nb * S:].float() * vm, cref * vm) < 5e-3
+    dctx = (torch.randn(T, H, device="cuda") * 0.5).to(dtype) * mask.view(T, 1).to(dtype)
+    (cref * dctx[-nb * S:].float()).sum().backward()
+    dbias = torch.zeros(3 * H, device="cuda") if C().attn_bwd_fuses_dbias(S) else None
+    dqkv = C().op_attn_bwd(qkv, mask, kv_len, ctx, dctx, lse, B, S, A, None, 0.0, 0, 0, dbias)
+    assert rel_err(dqkv[-nb * S:], qf.grad) < 6e-3
+    if dbias is not None:
+        torch.testing.assert_close(dbias, dqkv.float().sum(0), rtol=5e-3, atol=0.5)
