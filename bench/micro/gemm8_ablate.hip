@@ -4,6 +4,7 @@
 // -DPDT_LAYOUT=0 (default) NT: A[M,K] B[N,K];  1 NN: A[M,K] B[K,N];  2 TN: A[K,M] B[K,N] with split-K fp32 slabs
 // (as many K slices as fill 256 workgroups).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -37,7 +38,13 @@ int main(int argc, char** argv) {
   using KK = pdt::Gemm8<_Float16, AKS, BKS>;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KK::LDS_BYTES));
   const int total = g.tiles_m * g.tiles_n * splits;
-  const int grid = total;
+  // argv[4]: workgroups of a persistent launch (0 = one workgroup per tile); needs full tiles and an even K-tile count
+  const int want = argc > 4 ? atoi(argv[4]) : 0;
+  const int grid = (want > 0 && 2 * want <= total && want % 8 == 0 && PDT_LAYOUT != 2 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0) ? want : total;
+  if (grid < total) {  // ticket counters of a persistent launch: 2 fixed tiles per workgroup already handed out
+    std::vector<uint32_t> init(8, 2u * (grid / 8));
+    CK(hipMalloc(&g.sync, 32)); CK(hipMemcpy(g.sync, init.data(), 32, hipMemcpyHostToDevice));
+  }
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
@@ -48,6 +55,28 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(ev1)); CK(hipEventSynchronize(ev1));
     float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
     if (ms / 10 < best) best = ms / 10;
+  }
+  if (PDT_ABLATE == 0 && PDT_LAYOUT != 2) {  // spot check against the host: 64 random elements
+    // a fresh launch into a zeroed C (after the 55 launches above: the ticket counters must have been re-armed every time)
+    CK(hipMemset(C, 0, (size_t)M * N * 2));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<_Float16> hc((size_t)M * N);
+    CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0;
+    // one sample in every 256x256 tile + random ones
+    const int tm_n = M / 256 > 0 ? M / 256 : 1, tn_n = N / 256 > 0 ? N / 256 : 1;
+    const int nsamp = tm_n * tn_n + 64;
+    for (int s = 0; s < nsamp; ++s) {
+      int m, n;
+      if (s < tm_n * tn_n) { m = (s / tn_n) * 256 + rand() % 256; n = (s % tn_n) * 256 + rand() % 256; if (m >= M) m = M - 1; if (n >= N) n = N - 1; }
+      else { m = rand() % M; n = rand() % N; }
+      double ref = 0;
+      for (int k = 0; k < K; ++k) ref += (double)(float)ha[(size_t)m * K + k] * (double)(float)(BKS ? hb[(size_t)k * N + n] : hb[(size_t)n * K + k]);
+      const double err = fabs((double)(float)hc[(size_t)m * N + n] - ref) / (fabs(ref) + 1.0);
+      if (err > worst) worst = err;
+    }
+    printf("grid=%d  worst relative error of %d sampled outputs (every tile): %.2e %s\n", grid, nsamp, worst, worst < 2e-2 ? "ok" : "MISMATCH");
   }
   printf("layout=%d phases=%d ablate=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
   return 0;

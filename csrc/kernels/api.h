@@ -52,6 +52,8 @@ typedef struct PdtGemm {
   // second kernel that also applies the epilogue.  pdt_gemm_splits() says how many slices a shape wants.
   float* ws;
   int ws_splits;
+  // (set by the launcher) per-XCD ticket counters of a persistent launch of the 256x256 ping-pong kernel
+  uint32_t* sync;
 } PdtGemm;
 
 // tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves, one barrier per K-tile), 2 = 256x256 ping-pong

@@ -55,7 +55,6 @@ struct GemmKernel {
     uint32_t kstep;          // bytes to advance per K-tile
 
     __device__ __forceinline__ void init(const T* X, int ld, int xdim, int x0, int kb, int klen, int tid) {
-      constexpr int pitch = BX * 2;  // K-strided image row pitch (bytes)
       const T* base;
       uint32_t records;
       const int xavail = min(BX, xdim - x0);
@@ -73,6 +72,12 @@ struct GemmKernel {
         records = 0;
       }
       rsrc = pdt_make_rsrc(base, records);
+      offsets(ld, xavail, tid);
+    }
+    // per-lane offsets of the window (they depend on the operand's pitch and on how much of the window is inside
+    // the matrix, not on where the window starts)
+    __device__ __forceinline__ void offsets(int ld, int xavail, int tid) {
+      constexpr int pitch = BX * 2;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int pos = p * NT * 16 + tid * 16;
@@ -91,6 +96,13 @@ struct GemmKernel {
           kcol[p] = c * 8;
         }
       }
+    }
+    // point the loader at another FULL window of the same operand (same lane offsets, new base): what a
+    // persistent kernel does between output tiles
+    __device__ __forceinline__ void retarget(const T* X, int ld, int x0, int kb, int klen) {
+      const T* base = KS ? X + (size_t)kb * ld + x0 : X + (size_t)x0 * ld + kb;
+      const uint32_t records = KS ? (uint32_t)(((size_t)(klen - 1) * ld + BX) * 2) : (uint32_t)(((size_t)(BX - 1) * ld + klen) * 2);
+      rsrc = pdt_make_rsrc(base, records);
     }
     // issue this operand's LDS-DMA loads for K-tile `kt` into `dst` (wave-uniform LDS base of the image)
     __device__ __forceinline__ void issue(char* dst, int kt, int klen, int wave) {

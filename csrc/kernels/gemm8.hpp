@@ -45,7 +45,8 @@ struct Gemm8 {
   static constexpr int NT = 512, BK = 64;
   static constexpr int HALF_BYTES = 128 * 128;         // one half tile
   static constexpr int BUF_BYTES = 4 * HALF_BYTES;     // A0 | B0 | B1 | A1
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  static constexpr int LDS_RING_BYTES = 2 * BUF_BYTES;
+  static constexpr int LDS_BYTES = LDS_RING_BYTES + 4 * (32 * 256);  // ring + epilogue staging of waves 0-3 = 160 KiB
   using LoaderA = typename Base::template Loader<AKS, 128, 2>;
   using LoaderB = typename Base::template Loader<BKS, 128, 2>;
 
@@ -67,45 +68,75 @@ struct Gemm8 {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
+    // One output tile per workgroup (gridDim.x == number of tiles), or a persistent launch: fewer workgroups than
+    // tiles (host-checked: every tile full, an even number of K-tiles, no K split, >= 2 tiles per workgroup).  A
+    // persistent workgroup keeps the LDS ring running across output tiles - the last phases of a tile stage the
+    // first K-tiles of the next one, so its first loads fly under the epilogue instead of in front of an idle
+    // matrix pipe.  Tiles are handed out per XCD (each XCD owns the contiguous run of tile ids xcd_remap gives
+    // it): a workgroup's first two tiles are fixed, further ones are drawn from the XCD's ticket counter in
+    // g.sync, one tile ahead (the draw is issued at the start of an epilogue and is back when it ends).  A
+    // workgroup that is scheduled late (CUs busy with another stream's kernels) therefore costs at most its two
+    // fixed tiles, not a fixed 1/256 of the problem.
     const int ntiles = g.tiles_m * g.tiles_n;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = id / ntiles, t_ = id % ntiles;
-    int tm, tn;
-    tile_coords(t_, g.tiles_m, g.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int kb = split * g.k_per_split;
-    const int klen = min(g.K - kb, g.k_per_split);
-    const int nkt = (klen + BK - 1) / BK;
-
+    const int total = ntiles * g.splits;
+    const bool persistent = (int)gridDim.x < total;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    const int q_ = total >> 3, r_ = total & 7;
+    const int xcd_count = q_ + (xcd < r_ ? 1 : 0);                                            // tiles of this XCD
+    const int xcd_start = xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;        // first tile id
+    int cur = xcd_remap(blockIdx.x, total);  // == xcd_start + (blockIdx.x >> 3)
+    int nxt = (persistent && (int)(blockIdx.x >> 3) + per_xcd < xcd_count) ? cur + per_xcd : -1;
+    auto locate = [&](int id, int& tm_, int& tn_, int& split_) {
+      split_ = id / ntiles;
+      tile_coords(id - split_ * ntiles, g.tiles_m, g.tiles_n, tm_, tn_);
+    };
     LoaderA la0, la1;
     LoaderB lb0, lb1;
-    la0.init((const T*)g.A, g.lda, g.M, m0, kb, klen, tid);
-    la1.init((const T*)g.A, g.lda, g.M, m0 + 128, kb, klen, tid);
-    lb0.init((const T*)g.B, g.ldb, g.N, n0, kb, klen, tid);
-    lb1.init((const T*)g.B, g.ldb, g.N, n0 + 128, kb, klen, tid);
+    int klen;
+    {
+      int tm, tn, split;
+      locate(cur, tm, tn, split);
+      const int kb = split * g.k_per_split;
+      klen = min(g.K - kb, g.k_per_split);  // (persistent launches: the same for every tile)
+      la0.init((const T*)g.A, g.lda, g.M, tm * 256, kb, klen, tid);
+      la1.init((const T*)g.A, g.lda, g.M, tm * 256 + 128, kb, klen, tid);
+      lb0.init((const T*)g.B, g.ldb, g.N, tn * 256, kb, klen, tid);
+      lb1.init((const T*)g.B, g.ldb, g.N, tn * 256 + 128, kb, klen, tid);
+    }
+    const int nkt = (klen + BK - 1) / BK;
 
     float4v acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     // stage(i, tile): issue half tile i (0:A0 1:B0 2:B1 3:A1) of K-tile `tile` into ring buffer tile&1.
-    // Tiles at or beyond nkt read out of bounds (kt*kstep runs past `records`, or the K check fails): zeros.
+    // Tiles at or beyond nkt belong to the next output tile of a persistent workgroup (the loaders have been
+    // retargeted by then, kt_bias = nkt); without a next tile they read out of bounds (kt*kstep runs past
+    // `records`, or the K check fails) and the buffer unit writes zeros.
 #define PDT_STAGE(I, TILE)                                                                   \
   do {                                                                                       \
     if (PDT_ABLATE == 1 && (TILE) > 1) break;                                                \
     char* b_ = smem + ((TILE)&1) * BUF_BYTES;                                                \
-    if ((I) == 0) la0.issue(b_ + OFF_A0, (TILE), klen, wave);                                \
-    else if ((I) == 1) lb0.issue(b_ + OFF_B0, (TILE), klen, wave);                           \
-    else if ((I) == 2) lb1.issue(b_ + OFF_B1, (TILE), klen, wave);                           \
-    else la1.issue(b_ + OFF_A1, (TILE), klen, wave);                                         \
+    const int kt_ = ((TILE) >= nkt && has_next) ? (TILE) - nkt : (TILE);                     \
+    if ((I) == 0) la0.issue(b_ + OFF_A0, kt_, klen, wave);                                   \
+    else if ((I) == 1) lb0.issue(b_ + OFF_B0, kt_, klen, wave);                              \
+    else if ((I) == 2) lb1.issue(b_ + OFF_B1, kt_, klen, wave);                              \
+    else la1.issue(b_ + OFF_A1, kt_, klen, wave);                                            \
   } while (0)
 
     // prologue: tile 0 completely + the first two half tiles of tile 1
-    PDT_STAGE(0, 0); PDT_STAGE(1, 0); PDT_STAGE(2, 0); PDT_STAGE(3, 0);
-    PDT_STAGE(0, 1); PDT_STAGE(1, 1);
+    {
+      const bool has_next = false;
+      PDT_STAGE(0, 0); PDT_STAGE(1, 0); PDT_STAGE(2, 0); PDT_STAGE(3, 0);
+      PDT_STAGE(0, 1); PDT_STAGE(1, 1);
+    }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+
+    for (;;) {
+    const bool has_next = nxt >= 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 has landed (every wave waited for its own share before this barrier)
     __builtin_amdgcn_s_barrier();
     // the second wave group runs one barrier behind the first from here on
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -140,6 +171,26 @@ struct Gemm8 {
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
 
+    // persistent launch: the last K-tiles of this output tile stage the first ones of the next
+#define PDT_RETARGET_A0B0()                                                                  \
+  do {                                                                                       \
+    if (has_next && t == nkt - 2) {                                                          \
+      int ntm_, ntn_, ns_;                                                                   \
+      locate(nxt, ntm_, ntn_, ns_);                                                \
+      la0.retarget((const T*)g.A, g.lda, ntm_ * 256, ns_ * g.k_per_split, klen);             \
+      lb0.retarget((const T*)g.B, g.ldb, ntn_ * 256, ns_ * g.k_per_split, klen);             \
+    }                                                                                        \
+  } while (0)
+#define PDT_RETARGET_B1A1()                                                                  \
+  do {                                                                                       \
+    if (has_next && t == nkt - 1) {                                                          \
+      int ntm_, ntn_, ns_;                                                                   \
+      locate(nxt, ntm_, ntn_, ns_);                                                \
+      lb1.retarget((const T*)g.B, g.ldb, ntn_ * 256 + 128, ns_ * g.k_per_split, klen);       \
+      la1.retarget((const T*)g.A, g.lda, ntm_ * 256 + 128, ns_ * g.k_per_split, klen);       \
+    }                                                                                        \
+  } while (0)
+
 #if PDT_PHASES == 4
     for (int t = 0; t < nkt; ++t) {
       const char* buf = smem + (t & 1) * BUF_BYTES;
@@ -152,6 +203,7 @@ struct Gemm8 {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = fragA(buf + OFF_A0, arow + mi * 16, ks, lane);
+      PDT_RETARGET_B1A1();
       PDT_STAGE(2, t + 1);
       PDT_SYNC_LOADS();
       PDT_MFMA_QUADRANT(0, fb0, 0);
@@ -170,6 +222,7 @@ struct Gemm8 {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = fragA(buf + OFF_A1, arow + mi * 16, ks, lane);
+      PDT_RETARGET_A0B0();
       PDT_STAGE(0, t + 2);
       PDT_SYNC_LOADS();
       PDT_MFMA_QUADRANT(1, fb1, 1);
@@ -209,6 +262,7 @@ struct Gemm8 {
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fb1[ni][ks] = fragB(buf + OFF_B1, bcol + ni * 16, ks, lane);
+      PDT_RETARGET_B1A1();
       PDT_STAGE(2, t + 1);
       PDT_STAGE(3, t + 1);
       PDT_SYNC_LOADS2();
@@ -219,6 +273,7 @@ struct Gemm8 {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = fragA(buf + OFF_A1, arow + mi * 16, ks, lane);
+      PDT_RETARGET_A0B0();
       PDT_STAGE(0, t + 2);
       PDT_STAGE(1, t + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -229,35 +284,87 @@ struct Gemm8 {
     }
 #undef PDT_SYNC_LOADS2
 #endif
-    // re-align the two wave groups, drain the (zero-filling) DMA still in flight, then reuse LDS
+    // re-align the two wave groups: every wave has retired its last fragment reads.  The DMA still in flight
+    // (the next tile's first K-tiles, or zero fill) targets buffer 0 and the A0/B0 slots of buffer 1; the epilogue
+    // stages through the B1/A1 slots of buffer 1 and the 32 KiB behind the ring, so nothing has to drain here.
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#undef PDT_STAGE
-#undef PDT_MFMA_QUADRANT
-#undef PDT_SYNC_LOADS
-#undef PDT_END_PHASE
+    __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------------------------ epilogue
-    const int lm = lane & 15, lg = lane >> 4;
-    if (g.epi == EPI_SLAB_F32) {
-      float* slab = (float*)g.C + (size_t)split * g.M * g.ldc;
+    // The epilogue re-reads its (many) arguments from the kernel-argument segment for every tile, through a
+    // pointer the optimiser cannot see through: hoisted out of the tile loop they would sit in ~40 SGPRs during
+    // the main loop.  (PdtGemm is the kernel's only argument: offset 0 of the segment.)
+    auto kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kargs));
+    const PdtGemm& ge = *(const PdtGemm*)kargs;
+    int tm, tn, split;
+    locate(cur, tm, tn, split);
+    const int m0 = tm * 256, n0 = tn * 256;
+    // draw the ticket of the tile after next: the atomic's round trip hides under the epilogue
+    uint32_t ticket = 0;
+    const bool draw = has_next && tid == 0;
+    if (draw) ticket = __hip_atomic_fetch_add(ge.sync + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (likewise the epilogue's per-lane address arithmetic: recomputed per tile from an opaque copy of the lane id
+    // instead of living in registers through the main loop)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lm = lane_e & 15, lg = lane_e >> 4;
+    if (PDT_ABLATE == 4) {  // no epilogue: keep the accumulators alive, store nothing
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else if (ge.epi == EPI_SLAB_F32) {  // (weight gradients: never persistent)
+      float* slab = (float*)ge.C + (size_t)split * ge.M * ge.ldc;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int m = m0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + lm;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + lg * 4;
-          if (m < g.M && n < g.N) *reinterpret_cast<float4v*>(slab + (size_t)m * g.ldc + n) = acc[i][j];
+          if (m < ge.M && n < ge.N) *reinterpret_cast<float4v*>(slab + (size_t)m * ge.ldc + n) = acc[i][j];
         }
       }
-      return;
+    } else {
+      // staged column block jc = lane&7: n-half jc>>2, 8 columns at (jc&3)*8; staged row block pair ip:
+      // m-half ip>>1, rows (ip&1)*32.. of the wave's 64
+      char* stg = wave < 4 ? smem + LDS_RING_BYTES + wave * (32 * 256)
+                           : smem + BUF_BYTES + OFF_B1 + (wave - 4) * (32 * 256);
+      Base::template staged_epilogue<4>(ge, acc, stg, n0 + ((lane_e & 7) >> 2) * 128 + wc * 32 + (lane_e & 3) * 8,
+                                        [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, tm * 2 + wr, lane_e);
     }
-    // staged column block jc = lane&7: n-half jc>>2, 8 columns at (jc&3)*8; staged row block pair ip:
-    // m-half ip>>1, rows (ip&1)*32.. of the wave's 64
-    Base::template staged_epilogue<4>(g, acc, smem + wave * (32 * 256),
-                                      n0 + ((lane & 7) >> 2) * 128 + wc * 32 + (lane & 3) * 8,
-                                      [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, tm * 2 + wr, lane);
+    // the loads staged for the next tile (K-tile 0 and half of K-tile 1) were issued before the epilogue's own
+    // memory operations: an empty counter means they have landed (and, at the end, that no zero fill is in flight)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!has_next) break;
+    // hand the drawn tile id (or -1: the XCD's tiles are all taken) to the other waves through the first word of
+    // wave 0's staging area; they read it behind the barrier at the top of the next tile
+    int* mailbox = reinterpret_cast<int*>(smem + LDS_RING_BYTES);
+    if (draw) {
+      *mailbox = (int)ticket < xcd_count ? xcd_start + (int)ticket : -1;
+      // every workgroup of the XCD draws exactly one ticket beyond the end: the last of them re-arms the counter
+      // (the first 2 * per_xcd tickets are the fixed tiles) for the next launch on this stream
+      if ((int)ticket == xcd_count + per_xcd - 1) ge.sync[xcd] = 2u * per_xcd;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cur = nxt;
+    __builtin_amdgcn_s_barrier();
+    nxt = __builtin_amdgcn_readfirstlane(*mailbox);
+    {
+      // the lane offsets are the same for every (full) tile: recomputed here from an opaque copy of the thread
+      // id so that they do not occupy registers across the epilogue
+      int tid2 = tid;
+      asm volatile("" : "+v"(tid2));
+      la0.offsets(g.lda, 128, tid2); la1.offsets(g.lda, 128, tid2);
+      lb0.offsets(g.ldb, 128, tid2); lb1.offsets(g.ldb, 128, tid2);
+    }
+    }  // persistent tile loop
+#undef PDT_STAGE
+#undef PDT_MFMA_QUADRANT
+#undef PDT_SYNC_LOADS
+#undef PDT_END_PHASE
+#undef PDT_RETARGET_A0B0
+#undef PDT_RETARGET_B1A1
   }
 };
 

@@ -1,6 +1,8 @@
 // Per-layout instantiation helper: each gemm_<layout>.hip defines PDT_AKS / PDT_BKS / PDT_LAYOUT_FN and
 // includes this file, so the three operand layouts compile in parallel translation units.
 #pragma once
+#include <mutex>
+#include <unordered_map>
 #include "gemm8.hpp"
 
 namespace pdt {
@@ -95,6 +97,28 @@ static int launch_tile(PdtGemm& g, hipStream_t stream) {
   return launch(g);
 }
 
+constexpr int kPersistentWorkgroups = 256;  // one per CU (a workgroup owns all 160 KiB of LDS)
+
+// Ticket counters of persistent launches: 8 words (one per XCD) per stream - launches on one stream are ordered,
+// and the kernel leaves the counters re-armed (2 fixed tiles per workgroup already handed out) when it ends.
+// Returns nullptr when the stream is being captured and has no counters yet (no allocation inside a capture).
+static uint32_t* persistent_counters(hipStream_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, uint32_t*> table;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = table.find(stream);
+  if (it != table.end()) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  uint32_t* p = nullptr;
+  if (hipMalloc(&p, 8 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+  uint32_t init[8];
+  for (auto& w : init) w = 2u * (kPersistentWorkgroups / 8);
+  if (hipMemcpy(p, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  table.emplace(stream, p);
+  return p;
+}
+
 template <typename T>
 static int launch_pingpong(PdtGemm& g, hipStream_t stream) {
   using K = Gemm8<T, PDT_AKS, PDT_BKS>;
@@ -112,7 +136,14 @@ static int launch_pingpong(PdtGemm& g, hipStream_t stream) {
     g.splits = 1;
     g.k_per_split = ((g.K + 63) / 64) * 64;
   }
-  const int grid = g.tiles_m * g.tiles_n * g.splits;
+  int grid = g.tiles_m * g.tiles_n * g.splits;
+  // persistent launch (one workgroup per CU walks several output tiles, see Gemm8::run): needs every tile full, an
+  // even number of K-tiles, no K split and at least two tiles per workgroup; PDT_GEMM_PERSIST=0 turns it off
+  static const bool allow_persist = [] { const char* e = getenv("PDT_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
+  g.sync = nullptr;
+  if (allow_persist && g.epi != PDT_EPI_SLAB_F32 && grid >= 2 * kPersistentWorkgroups && g.M % 256 == 0 && g.N % 256 == 0 &&
+      g.K % 128 == 0 && (g.sync = persistent_counters(stream)) != nullptr)
+    grid = kPersistentWorkgroups;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, stream, g);
   return (int)hipGetLastError();
 }

@@ -483,6 +483,50 @@ def test_gelu_epilogue_matches_erf_gelu_closely():
     assert (d[0].float() - bf.grad).abs().max().item() <= 2e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_persistent_launch(layout, dtype):
+    """At least 512 full output tiles and an even K-tile count: the ping-pong kernel runs as 256 persistent
+    workgroups that stage the next tile's first K-tiles under the epilogue and draw their third and later
+    tiles from per-XCD ticket counters.  Every epilogue kind, tile counts that do not divide evenly, K of 2, 4
+    and 6 K-tiles; values checked against fp32 and bit-identical between runs (every launch re-arms the counters)."""
+    torch.manual_seed(13)
+    for (M, N, K) in [(8192, 4608, 256), (4096, 8448, 384), (2048, 16640, 128)]:  # 576 / 528 / 520 tiles
+        A = (torch.randn(M, K, device="cuda") * 0.3).to(dtype)
+        rt, at = tol(dtype)
+        if layout == "nt":
+            W = (torch.randn(N, K, device="cuda") * 0.1).to(dtype)
+            b = torch.randn(N, device="cuda").to(dtype)
+            res = torch.randn(M, N, device="cuda").to(dtype)
+            pre = A.float() @ W.float().t()
+            out = C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, 2)
+            assert rel_err(out, pre) < 5e-3
+            assert torch.equal(out, C().op_gemm("nt", A, W, 0, None, None, None, None, 0.0, 0, 0, 2))
+            aux = torch.empty(M, N, device="cuda", dtype=dtype)
+            act = C().op_gemm("nt", A, W, 2, b, None, aux, None, 0.0, 0, 0, 2)
+            assert rel_err(act, F.gelu(pre + b.float())) < 1e-2
+            assert rel_err(aux, gelu_grad(pre + b.float())) < 1e-2
+            z = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(), 0.0, 0, 0, 2)
+            assert rel_err(z, pre + b.float() + res.float()) < 1e-2
+            # dropout: the same mask as the one-tile-per-workgroup 128x128 kernel (counters depend on (m, n) only)
+            d2 = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(3, 1), 0.1, 2, 5, 2)
+            d0 = C().op_gemm("nt", A, W, 3, b, res, None, rng_state(3, 1), 0.1, 2, 5, 0)
+            torch.testing.assert_close(d2.float(), d0.float(), rtol=rt, atol=at)
+        else:
+            W = (torch.randn(K, N, device="cuda") * 0.1).to(dtype)
+            ref = A.float() @ W.float()
+            out = C().op_gemm("nn", A, W, 0, None, None, None, None, 0.0, 0, 0, 2)
+            assert rel_err(out, ref) < 5e-3
+            dg = gelu_grad(torch.randn(M, N, device="cuda")).to(dtype)
+            cs = torch.zeros(N, device="cuda")
+            du = C().op_gemm("nn", A, W, 4, None, None, dg, None, 0.0, 0, 0, 2, cs)
+            assert rel_err(du, ref * dg.float()) < 1e-2
+            torch.testing.assert_close(cs, du.float().sum(0), rtol=5e-3, atol=0.5)
+            res = torch.randn(M, N, device="cuda").to(dtype)
+            dx = C().op_gemm("nn", A, W, 5, None, res, None, None, 0.0, 0, 0, 2)
+            assert rel_err(dx, ref + res.float()) < 1e-2
+
+
 # ------------------------------------------------------------------------------ large token counts
 def test_kernels_at_131072_tokens():
     """Per-GPU batch 1024 x 128 tokens (what the 288 GB of HBM are sized for): every index computation of the
