@@ -1,5 +1,7 @@
+"""Device-memory level after forward / backward / optimizer step of BERT-large (leak and peak check): python tools/mem_probe.py [batch]"""
 import torch, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_distributed_training_amd.engine import Engine
 from pytorch_distributed_training_amd.models.bert import build_model
 from pytorch_distributed_training_amd.optim import AdamW
