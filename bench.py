@@ -45,6 +45,9 @@ def main() -> None:
     ap.add_argument("--accum", type=int, default=1, help="micro-batches per optimizer step")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
+    ap.add_argument("--comm", default=None, choices=[None, "c10d", "rccl"],
+                    help="gradient all-reduce through torch's RCCL process group (c10d, default) or through the framework's "
+                         "own RCCL communicator and communication stream (rccl)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="single GPU only: run the data-parallel machinery anyway (1-rank RCCL group, every bucket "
                          "all-reduce really issued on RCCL's stream) to see what the gradient path costs besides the wire")
@@ -66,7 +69,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm)
+    eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm, comm_backend=args.comm)
     if eng.device.type != "cuda":
         raise SystemExit("bench.py needs a GPU")
     torch.manual_seed(42)
@@ -76,7 +79,7 @@ def main() -> None:
     if args.rehearse_dp:
         from pytorch_distributed_training_amd.parallel.dp import DataParallel
 
-        model = DataParallel(model, model.arena, None, comm)
+        model = DataParallel(model, model.arena, None, comm, comm_backend=args.comm)
         eng._models[-1] = model
     sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
     model.train()
@@ -151,6 +154,7 @@ def main() -> None:
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
+                       "comm_backend": args.comm or os.environ.get("PDT_COMM", "c10d"),
                        "hip_graph": bool(args.graph),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,
                        "optimizer": "fused AdamW + dynamic loss scale",

@@ -109,7 +109,7 @@ def build(jobs: int = 8, verbose: bool = False, force: bool = False, kernel_defi
     objs = [t[1] for t in tasks]
     if rebuilt or not os.path.exists(OUT):
         link = [os.environ.get("CXX", "g++"), "-shared", "-o", OUT] + objs + [f"-L{tlib}", "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python",
-                                                      "-lc10_hip", "-ltorch_hip", "-lamdhip64"]
+                                                      "-lc10_hip", "-ltorch_hip", "-lamdhip64", "-lrccl"]
         r = subprocess.run(link, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed: {' '.join(link)}\n{r.stdout}\n{r.stderr}")

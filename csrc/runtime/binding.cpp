@@ -589,6 +589,7 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
 
 }  // namespace
 
+void bind_rccl_comm(py::module_& m);  // rccl_comm.cpp
 void bind_reducer(py::module_& m);    // reducer.cpp
 void bind_wordpiece(py::module_& m);  // wordpiece.cpp
 
@@ -628,6 +629,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "drain the device after every native launch and report a fault at the op that caused it");
   m.def("debug_sync_count", [] { return g_debug_sync_count; });
   m.def("attn_bwd_fuses_dbias", [](int64_t S) { return pdt_attn_bwd_fuses_dbias((int)S) != 0; });
+  bind_rccl_comm(m);  // (before the reducer: its constructor signature names RcclComm)
   bind_reducer(m);
   bind_wordpiece(m);
 }

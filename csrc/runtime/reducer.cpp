@@ -10,12 +10,16 @@
 // RCCL runs it on its own HIP stream (ordered after the producing kernels by an event) while the compute
 // stream continues with the next layer's backward.
 //
-// The collective backend is a c10d::ProcessGroup: "nccl" (= RCCL over xGMI) on GPUs, "gloo" for the
-// CPU plumbing configuration - the identical C++ code path is exercised by the CPU multi-process tests.
+// The collective backend is either a c10d::ProcessGroup - "nccl" (= RCCL over xGMI) on GPUs, "gloo" for the
+// CPU plumbing configuration; the identical C++ code path is exercised by the CPU multi-process tests - or
+// this framework's own RcclComm (rccl_comm.h): RCCL's C API on a communication stream the reducer forks
+// from the compute stream per bucket and joins once at the end of backward.
 #include <torch/extension.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/csrc/distributed/c10d/Types.hpp>
 #include <torch/csrc/distributed/c10d/Work.hpp>
+
+#include "rccl_comm.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -32,8 +36,19 @@ class GradBucketReducer {
  public:
   GradBucketReducer(PG pg, Tensor arena, std::vector<int64_t> bounds, std::vector<int64_t> expected, bool average,
                     int64_t comm_dtype_code)
-      : pg_(std::move(pg)), arena_(std::move(arena)), bounds_(std::move(bounds)), expected_(std::move(expected)),
-        average_(average) {
+      : GradBucketReducer(std::move(pg), nullptr, std::move(arena), std::move(bounds), std::move(expected), average,
+                          comm_dtype_code) {}
+  GradBucketReducer(std::shared_ptr<pdt::RcclComm> comm, Tensor arena, std::vector<int64_t> bounds,
+                    std::vector<int64_t> expected, bool average, int64_t comm_dtype_code)
+      : GradBucketReducer(PG(), std::move(comm), std::move(arena), std::move(bounds), std::move(expected), average,
+                          comm_dtype_code) {}
+
+ private:
+  GradBucketReducer(PG pg, std::shared_ptr<pdt::RcclComm> comm, Tensor arena, std::vector<int64_t> bounds,
+                    std::vector<int64_t> expected, bool average, int64_t comm_dtype_code)
+      : pg_(std::move(pg)), rccl_(std::move(comm)), arena_(std::move(arena)), bounds_(std::move(bounds)),
+        expected_(std::move(expected)), average_(average) {
+    TORCH_CHECK(bool(pg_) != bool(rccl_), "exactly one collective backend (process group or RcclComm) is needed");
     // wire dtype of the all-reduce: 0 = the arena's own (fp32), 1 = float16, 2 = bfloat16
     if (comm_dtype_code == 1) comm_dtype_ = at::kHalf;
     if (comm_dtype_code == 2) comm_dtype_ = at::kBFloat16;
@@ -45,8 +60,9 @@ class GradBucketReducer {
       TORCH_CHECK(bounds_[i] < bounds_[i + 1], "empty bucket ", i);
       views_.push_back(arena_.narrow(0, bounds_[i], bounds_[i + 1] - bounds_[i]));
     }
-    world_ = pg_->getSize();
-    is_nccl_ = pg_->getBackendName() == "nccl";
+    world_ = rccl_ ? (int)rccl_->size() : pg_->getSize();
+    is_nccl_ = rccl_ ? true : pg_->getBackendName() == "nccl";
+    if (rccl_) TORCH_CHECK(arena_.is_cuda() && arena_.get_device() == rccl_->device(), "arena is not on the communicator's GPU");
     // PDT_FORCE_COLLECTIVES=1 issues the collectives even in a 1-rank group (exercises the RCCL call path on
     // a single-GPU test box)
     const char* force = std::getenv("PDT_FORCE_COLLECTIVES");
@@ -54,6 +70,7 @@ class GradBucketReducer {
     reset();
   }
 
+ public:
   // Start a backward pass.  sync=false is the no_sync() mode: gradients only accumulate locally.
   void begin(bool sync) {
     reset();
@@ -80,10 +97,13 @@ class GradBucketReducer {
     for (int b = next_; b < nb_; ++b) launch(b);
     next_ = nb_;
     const auto t0 = std::chrono::steady_clock::now();
+    if (rccl_ && launched_any_) rccl_->join();  // the compute stream waits for every bucket; the host does not
     for (int b = 0; b < nb_; ++b) {
-      if (!works_[b]) continue;
-      works_[b]->wait();
-      works_[b].reset();
+      if (!rccl_) {
+        if (!works_[b]) continue;
+        works_[b]->wait();
+        works_[b].reset();
+      }
       if (staged_[b].defined()) {
         views_[b].copy_(staged_[b]);
         staged_[b] = Tensor();
@@ -98,6 +118,13 @@ class GradBucketReducer {
   void broadcast(Tensor t, int64_t root, int64_t chunk_elems) {
     TORCH_CHECK(t.dim() == 1 && t.is_contiguous(), "broadcast expects a flat contiguous tensor");
     if (world_ == 1 && !force_) return;
+    if (rccl_) {
+      rccl_->fork();
+      for (int64_t o = 0; o < t.numel(); o += chunk_elems)
+        rccl_->broadcast_async(t.narrow(0, o, std::min(chunk_elems, t.numel() - o)), root);
+      rccl_->join();
+      return;
+    }
     std::vector<c10::intrusive_ptr<c10d::Work>> ws;
     for (int64_t o = 0; o < t.numel(); o += chunk_elems) {
       std::vector<Tensor> v{t.narrow(0, o, std::min(chunk_elems, t.numel() - o))};
@@ -129,6 +156,7 @@ class GradBucketReducer {
     staged_.assign(nb_, Tensor());
     order_.clear();
     next_ = 0;
+    launched_any_ = false;
   }
   void launch_ready_prefix() {
     while (next_ < nb_ && ready_[next_] >= expected_[next_]) launch(next_++);
@@ -141,21 +169,29 @@ class GradBucketReducer {
       staged_[b] = buf.to(*comm_dtype_);  // halve the bytes on the wire; accumulation stays fp32 in the arena
       buf = staged_[b];
     }
-    c10d::AllreduceOptions opts;
-    opts.reduceOp = (average_ && native_avg()) ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
-    std::vector<Tensor> v{buf};
-    works_[b] = pg_->allreduce(v, opts);
+    if (rccl_) {
+      // ordered after the kernels that produced the bucket (everything enqueued on the compute stream so far)
+      rccl_->fork();
+      rccl_->all_reduce_async(buf, average_);
+      launched_any_ = true;
+    } else {
+      c10d::AllreduceOptions opts;
+      opts.reduceOp = (average_ && native_avg()) ? c10d::ReduceOp::AVG : c10d::ReduceOp::SUM;
+      std::vector<Tensor> v{buf};
+      works_[b] = pg_->allreduce(v, opts);
+    }
     ++launches_;
     bytes_ += buf.numel() * buf.element_size();
   }
 
   PG pg_;
+  std::shared_ptr<pdt::RcclComm> rccl_;
   Tensor arena_;
   std::vector<int64_t> bounds_, expected_;
   bool average_;
   c10::optional<at::ScalarType> comm_dtype_;
   int nb_ = 0, world_ = 1, next_ = 0;
-  bool is_nccl_ = false, sync_ = true, active_ = false, force_ = false;
+  bool is_nccl_ = false, sync_ = true, active_ = false, force_ = false, launched_any_ = false;
   std::vector<Tensor> views_, staged_;
   std::vector<int64_t> ready_, order_;
   std::vector<c10::intrusive_ptr<c10d::Work>> works_;
@@ -168,6 +204,9 @@ void bind_reducer(py::module_& m) {
   py::class_<GradBucketReducer>(m, "GradBucketReducer")
       .def(py::init<PG, at::Tensor, std::vector<int64_t>, std::vector<int64_t>, bool, int64_t>(),
            py::arg("process_group"), py::arg("arena"), py::arg("bounds"), py::arg("expected"), py::arg("average") = true,
+           py::arg("comm_dtype") = 0)
+      .def(py::init<std::shared_ptr<pdt::RcclComm>, at::Tensor, std::vector<int64_t>, std::vector<int64_t>, bool, int64_t>(),
+           py::arg("rccl_comm"), py::arg("arena"), py::arg("bounds"), py::arg("expected"), py::arg("average") = true,
            py::arg("comm_dtype") = 0)
       .def("begin", &GradBucketReducer::begin, py::arg("sync") = true)
       .def("mark_ready", &GradBucketReducer::mark_ready, py::arg("bucket"), py::arg("count") = 1)

@@ -62,6 +62,7 @@ class TrainConfig:
     mp_layout: str = "pipeline"  # "pipeline" (2-stage layer split) | "towers" (TriBert branch ensemble)
     comm_dtype: Optional[str] = None  # None|fp16|bf16: wire dtype of the gradient all-reduce
     min_bucket_mb: float = 4.0
+    comm_backend: Optional[str] = None  # None|c10d|rccl: torch's RCCL process group, or the framework's own RcclComm
     # checkpointing
     output_dir: Optional[str] = None
     resume: Optional[str] = None

@@ -77,7 +77,7 @@ class EngineOptimizer:
 class Engine:
     def __init__(self, fp16: bool = False, cpu: bool = False, bf16: bool = False, seed: int = 42,
                  comm_dtype: Optional[torch.dtype] = None, min_bucket_mb: float = 4.0, process_group=None,
-                 init_scale: float = 2.0 ** 16, native: Optional[bool] = None):
+                 init_scale: float = 2.0 ** 16, native: Optional[bool] = None, comm_backend: Optional[str] = None):
         if fp16 and bf16:
             raise ValueError("choose one of fp16 / bf16")
         self.env, self.device = launch.init_distributed(cpu=cpu)
@@ -101,6 +101,8 @@ class Engine:
             self.distributed_type = DistributedType.MULTI_GPU if on_gpu else DistributedType.MULTI_CPU
         self.seed = seed
         self.comm_dtype = comm_dtype
+        # gradient all-reduce through c10d's "nccl" backend (default) or the framework's own RcclComm ("rccl")
+        self.comm_backend = comm_backend
         self.min_bucket_elems = int(min_bucket_mb * (1 << 20) / 4)
         self.scaler = LossScaler(self.device, enabled=fp16 and on_gpu, init_scale=init_scale)
         self._models = []
@@ -152,7 +154,7 @@ class Engine:
             # distinct dropout streams per data-parallel rank, reproducible from (seed, rank)
             model.enable_native(arena, seed=self.seed * 100003 + self.process_index)
         if self.num_processes > 1:
-            model = DataParallel(model, arena, self.pg, self.comm_dtype)
+            model = DataParallel(model, arena, self.pg, self.comm_dtype, comm_backend=self.comm_backend)
         self._models.append(model)
         return model
 

@@ -1,0 +1,69 @@
+"""The framework's own RCCL communicator (csrc/runtime/rccl_comm.cpp) and its bootstrap.
+
+The reference never creates a communicator itself: ``Accelerator()`` does it for the data-parallel script
+(/root/reference/test_data_parallelism.py:55) and ``init_process_group("gloo")`` for the model-parallel one
+(/root/reference/test_model_parallelism.py:166-171).  Here the launcher's env-var rendezvous (torch's TCPStore
+behind ``init_process_group``) is only the *bootstrap channel*: group rank 0 creates an RCCL unique id, the id
+travels over that channel, and every rank opens a communicator on the RCCL C API with a HIP stream of its own.
+The bucket reducer (``GradBucketReducer(rccl_comm=...)``) and the pipeline's send/recv can then run on it
+without going through c10d.
+
+Selection: ``PDT_COMM=rccl`` (or ``Engine(comm_backend="rccl")``) - the default stays c10d's "nccl" backend,
+which drives the same RCCL library.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+_COMMS: Dict[int, object] = {}
+
+
+def backend_choice(explicit: Optional[str] = None) -> str:
+    """"c10d" or "rccl" (from the argument, else the PDT_COMM environment variable)."""
+    choice = (explicit or os.environ.get("PDT_COMM") or "c10d").lower()
+    if choice not in ("c10d", "rccl"):
+        raise ValueError(f"unknown communication backend {choice!r} (c10d | rccl)")
+    return choice
+
+
+def create_rccl_comm(group=None, device: Optional[torch.device] = None):
+    """Open (once per group) an RcclComm spanning the ranks of `group` (default: all ranks; a process that has
+    no process group gets a 1-rank communicator).  Collective over the group: every member must call it."""
+    from ..ops import native
+
+    key = id(group) if group is not None else 0
+    if key in _COMMS:
+        return _COMMS[key]
+    C = native()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device.type != "cuda":
+        raise ValueError("an RCCL communicator needs a GPU; CPU runs use the gloo process group")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    if world == 1:
+        uid = C.RcclComm.unique_id()
+    else:
+        # the id goes from group rank 0 to the rest over the already initialised process group
+        box = [C.RcclComm.unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group, device=device if dist.get_backend(group) == "nccl" else None)
+        uid = box[0]
+    with torch.cuda.device(index):
+        comm = C.RcclComm(uid, rank, world, index)
+    _COMMS[key] = comm
+    return comm
+
+
+def close_all() -> None:
+    """Orderly teardown of every communicator this process opened (collective: call it on every rank)."""
+    for comm in _COMMS.values():
+        comm.close()
+    _COMMS.clear()

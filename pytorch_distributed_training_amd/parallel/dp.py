@@ -94,11 +94,19 @@ class _PyReducer:
         return len(self.expected)
 
 
-def make_reducer(pg, arena: ParamArena, expected: List[int], average: bool = True, comm_dtype: Optional[torch.dtype] = None):
+def make_reducer(pg, arena: ParamArena, expected: List[int], average: bool = True, comm_dtype: Optional[torch.dtype] = None,
+                 comm_backend: Optional[str] = None):
+    """The C++ bucket reducer over `pg` (c10d: "nccl" = RCCL, or gloo) or, with ``comm_backend="rccl"`` /
+    ``PDT_COMM=rccl`` on a GPU, over this framework's own RCCL communicator spanning the same ranks."""
     code = {None: 0, torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[comm_dtype]
     from ..ops import available, native
+    from .comm import backend_choice, create_rccl_comm
 
     if available():
+        if backend_choice(comm_backend) == "rccl" and arena.device.type == "cuda" and (
+                not dist.is_initialized() or dist.get_backend(pg) == "nccl"):
+            comm = create_rccl_comm(None if pg is dist.group.WORLD else pg, arena.device)
+            return native().GradBucketReducer(comm, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
         return native().GradBucketReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
     if arena.device.type == "cuda":
         native()  # raises with the build hint: never fall back silently on a GPU box
@@ -109,7 +117,7 @@ class DataParallel(nn.Module):
     """Wrap an arena-backed model for data-parallel training over `process_group`."""
 
     def __init__(self, module: nn.Module, arena: ParamArena, process_group=None, comm_dtype: Optional[torch.dtype] = None,
-                 broadcast_from: Optional[int] = 0):
+                 broadcast_from: Optional[int] = 0, comm_backend: Optional[str] = None):
         super().__init__()
         self.module = module
         self.arena = arena
@@ -136,7 +144,7 @@ class DataParallel(nn.Module):
                         expected[seg.bucket] += 1
                         p.register_post_accumulate_grad_hook(self._make_hook(seg.bucket))
             expected = [max(1, e) for e in expected]
-        self.reducer = make_reducer(self.pg, arena, expected, True, comm_dtype)
+        self.reducer = make_reducer(self.pg, arena, expected, True, comm_dtype, comm_backend)
         if self.world_size > 1:
             self._verify_replicas()
         if broadcast_from is not None and self.world_size > 1:

@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .comm import backend_choice, create_rccl_comm
 from .dp import DataParallel
 from .groups import ParallelMesh
 from ..utils.profile import trace_range
@@ -67,10 +68,15 @@ def _split_batch(batch: Dict[str, torch.Tensor], m: int) -> List[Dict[str, torch
     return [{k: v[bounds[i]:bounds[i + 1]] for k, v in batch.items()} for i in range(m)]
 
 
-def _p2p(ops) -> None:
+def _p2p(ops, comm=None, pp: int = 2) -> None:
     """Run a group of point-to-point ops that must progress together.  On "nccl" (RCCL) they are fused into
     one group call on the communicator's stream; gloo has no device transport for send/recv, so GPU tensors
-    are staged through host memory there (CPU plumbing / single-GPU rehearsal only)."""
+    are staged through host memory there (CPU plumbing / single-GPU rehearsal only).  With `comm` (an RcclComm
+    over the replica's pipeline group, ``PDT_COMM=rccl``) the group goes straight to ncclSend / ncclRecv on the
+    framework's own communication stream; a peer's rank inside that group is its stage index."""
+    if comm is not None:
+        comm.p2p([0 if op.op is dist.isend else 1 for op in ops], [op.tensor for op in ops], [op.peer % pp for op in ops])
+        return
     if dist.get_backend() == "gloo" and any(op.tensor.is_cuda for op in ops):
         staged, works = [], []
         for op in ops:
@@ -105,6 +111,10 @@ class PipelineStage:
         self.first, self.last = mesh.is_first_stage, mesh.is_last_stage
         self.prev, self.next = mesh.peer(0), mesh.peer(1)
         self.timers = {"p2p_wait_s": 0.0}
+        self.comm = None
+        if (engine.device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl"
+                and backend_choice(getattr(engine, "comm_backend", None)) == "rccl"):
+            self.comm = create_rccl_comm(mesh.pp_group, engine.device)
 
     # -- communication -------------------------------------------------------------------------------
     def _buf(self, chunk: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -113,16 +123,16 @@ class PipelineStage:
 
     def _send(self, t: torch.Tensor, dst: int) -> None:
         with trace_range("pp.send"):
-            _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)])
+            _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)], self.comm, self.mesh.pp)
 
     def _recv(self, buf: torch.Tensor, src: int) -> torch.Tensor:
         with trace_range("pp.recv"):
-            _p2p([dist.P2POp(dist.irecv, buf, src)])
+            _p2p([dist.P2POp(dist.irecv, buf, src)], self.comm, self.mesh.pp)
         return buf
 
     def _send_recv(self, t: torch.Tensor, buf: torch.Tensor, peer: int) -> torch.Tensor:
         with trace_range("pp.send_recv"):
-            _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)])
+            _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)], self.comm, self.mesh.pp)
         return buf
 
     def _arm(self) -> None:
@@ -219,7 +229,8 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     print("MASTER_PORT:", os.environ.get("MASTER_PORT"))
     mesh = ParallelMesh(world_size, rank, pp=2).build_groups()
     engine = Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed, process_group=mesh.dp_group,
-                    min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale)
+                    min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale,
+                    comm_backend=cfg.comm_backend)
     model_cfg = preset(cfg.model) if not cfg.init_from else ckpt.EncoderConfig.load(cfg.init_from)
     train_ds, val_ds = build_datasets(cfg, model_cfg)
     accum, micro_bs = cfg.accumulation()

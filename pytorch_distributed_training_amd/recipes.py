@@ -94,7 +94,8 @@ def evaluate(engine: Engine, model, eval_dl, metric, dataset_len: int, dedupe: b
 def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict:
     engine = engine or Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed,
                               comm_dtype={None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[cfg.comm_dtype],
-                              min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale)
+                              min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale,
+                    comm_backend=cfg.comm_backend)
     # rank banner, as the reference prints it on every process
     print("LOCAL_RANK: ", engine.local_process_index)
     print("DEVICE: ", engine.device)
