@@ -4,7 +4,9 @@ The reference configures no timeouts (``init_process_group("gloo", ...)`` at
 /root/reference/test_model_parallelism.py:171 blocks forever if a peer dies) and has no checkpoints, so a
 torchrun restart starts from scratch.  :class:`StepWatchdog` is a host thread that aborts the process when
 no training step completes within ``timeout_s`` (a hung collective, a dead peer): the elastic launcher then
-restarts the worker group and the recipe resumes from the newest checkpoint.  ``inject_fault`` is the test
+restarts the worker group and the recipe resumes from the newest checkpoint.  On every tick it also polls the
+asynchronous error state of the framework's own RCCL communicators (``ncclCommGetAsyncError``: a peer that
+died, a link error) and aborts on the first error instead of waiting for the step timeout.  ``inject_fault`` is the test
 hook: ``PDT_INJECT_FAULT=rank:step`` makes that rank exit abruptly at that optimizer step.
 """
 from __future__ import annotations
@@ -31,6 +33,11 @@ class StepWatchdog:
 
     def _run(self) -> None:
         while not self._stop.wait(min(5.0, self.timeout_s / 4)):
+            err = poll_comm_errors()
+            if err:
+                print(f"[watchdog] rank {self.rank}: {err} - aborting so the launcher can restart the group",
+                      file=sys.stderr, flush=True)
+                os._exit(76)
             if time.monotonic() - self._last > self.timeout_s:
                 print(f"[watchdog] rank {self.rank}: no step for {self.timeout_s:.0f}s - aborting so the launcher "
                       "can restart the group", file=sys.stderr, flush=True)
@@ -38,6 +45,20 @@ class StepWatchdog:
 
     def close(self) -> None:
         self._stop.set()
+
+
+def poll_comm_errors() -> Optional[str]:
+    """First asynchronous RCCL error recorded on any communicator this process opened, or None."""
+    try:
+        from ..parallel.comm import _COMMS
+    except Exception:  # pragma: no cover - partial installs
+        return None
+    for comm in list(_COMMS.values()):
+        try:
+            comm.check_async_error()
+        except RuntimeError as e:
+            return str(e).splitlines()[0]
+    return None
 
 
 def inject_fault(rank: int, step: int) -> None:
