@@ -48,12 +48,21 @@ def main() -> None:
     ap.add_argument("--comm", default=None, choices=[None, "c10d", "rccl"],
                     help="gradient all-reduce through torch's RCCL process group (c10d, default) or through the framework's "
                          "own RCCL communicator and communication stream (rccl)")
+    ap.add_argument("--pp", type=int, default=1, choices=[1, 2],
+                    help="2 = every data-parallel replica is a 2-stage layer-split pipeline over a pair of GPUs (1F1B over "
+                         "send/recv); N GPUs = N/2 replicas.  The per-replica batch is 2 x --batch, so the work per GPU is "
+                         "the same as in the pure data-parallel run")
+    ap.add_argument("--micro-batches", type=int, default=8, help="pipeline micro-batches per optimizer step (--pp 2)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="single GPU only: run the data-parallel machinery anyway (1-rank RCCL group, every bucket "
                          "all-reduce really issued on RCCL's stream) to see what the gradient path costs besides the wire")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()
+    if os.environ.get("PDT_HANG_DUMP"):  # debugging aid: Python stacks of every thread after N seconds, then exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["PDT_HANG_DUMP"]), exit=True)
     if args.batch is None:
         args.batch = max(1, 131072 // args.seq_len)
 
@@ -61,6 +70,8 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     comm = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[args.comm_dtype]
+    if args.pp == 2:
+        return bench_pipeline(args, world, comm)
     if args.rehearse_dp:
         if world != 1:
             raise SystemExit("--rehearse-dp is a single-GPU rehearsal")
@@ -163,6 +174,75 @@ def main() -> None:
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_pipeline(args, world: int, comm) -> None:
+    """DP x 2-stage pipeline (the layout of /root/reference/test_model_parallelism.py: data parallel around a
+    model split over two devices) - rank = replica * 2 + stage, one GPU per rank."""
+    from pytorch_distributed_training_amd import launch
+    from pytorch_distributed_training_amd.models.config import preset
+    from pytorch_distributed_training_amd.parallel.groups import ParallelMesh
+    from pytorch_distributed_training_amd.parallel.pp import PipelineStage, build_stage
+
+    if world % 2:
+        raise SystemExit("--pp 2 needs an even number of ranks")
+    env, device = launch.init_distributed()
+    mesh = ParallelMesh(world, env.rank, pp=2).build_groups()
+    eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm, comm_backend=args.comm,
+                 process_group=mesh.dp_group)
+    if eng.device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU")
+    model_cfg = preset(args.model)
+    stage = build_stage(model_cfg, mesh.stage, 2, seed=42)
+    optimizer = AdamW(params=stage.parameters(), lr=2e-5, correct_bias=True)
+    stage, optimizer = eng.prepare(stage, optimizer)
+    sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
+    pipe = PipelineStage(stage, mesh, eng, micro_batches=args.micro_batches)
+    replica_batch = 2 * args.batch
+    # both stage ranks of a replica read the same batches (only hidden states cross the link)
+    pool = [fixed_batch(replica_batch, args.seq_len, model_cfg.vocab_size, eng.device, seed=1000 * mesh.replica + i)
+            for i in range(4)]
+    loss = None
+
+    def step(i: int):
+        out = pipe.train_step(pool[i % len(pool)])
+        pipe.optimizer_step(optimizer, sched)
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    box = [float(loss.item()) if (loss is not None and mesh.replica == 0) else None]
+    dist.broadcast_object_list(box, src=mesh.peer(1) if mesh.replica == 0 else 1)
+    global_batch = replica_batch * mesh.dp
+    value = global_batch * args.steps / dt
+    if env.rank == 0:
+        print(json.dumps({
+            "metric": f"training samples/sec (node) {_pretty(args.model)} seq{args.seq_len}",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic MRPC-shaped token batches (random-init weights)",
+            "final_loss": box[0], "tokens_per_s": round(value * args.seq_len, 1),
+            "config": {"model": args.model, "global_batch": global_batch, "per_replica_batch": replica_batch,
+                       "micro_batches": args.micro_batches, "seq_len": args.seq_len,
+                       "parallelism": f"dp{mesh.dp} x pp2 (1F1B)", "backend": dist.get_backend(),
+                       "comm_backend": args.comm or os.environ.get("PDT_COMM", "c10d"),
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "optimizer": "fused AdamW + dynamic loss scale", "dropout": 0.1},
+        }))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _pretty(model: str) -> str:

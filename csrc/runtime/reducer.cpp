@@ -62,6 +62,7 @@ class GradBucketReducer {
     }
     world_ = rccl_ ? (int)rccl_->size() : pg_->getSize();
     is_nccl_ = rccl_ ? true : pg_->getBackendName() == "nccl";
+    host_staged_ = !rccl_ && !is_nccl_ && arena_.is_cuda();
     if (rccl_) TORCH_CHECK(arena_.is_cuda() && arena_.get_device() == rccl_->device(), "arena is not on the communicator's GPU");
     // PDT_FORCE_COLLECTIVES=1 issues the collectives even in a 1-rank group (exercises the RCCL call path on
     // a single-GPU test box)
@@ -125,6 +126,15 @@ class GradBucketReducer {
       rccl_->join();
       return;
     }
+    if (host_staged_) {
+      Tensor host = t.to(at::kCPU);
+      std::vector<Tensor> v{host};
+      c10d::BroadcastOptions opts;
+      opts.rootRank = root;
+      pg_->broadcast(v, opts)->wait();
+      t.copy_(host);
+      return;
+    }
     std::vector<c10::intrusive_ptr<c10d::Work>> ws;
     for (int64_t o = 0; o < t.numel(); o += chunk_elems) {
       std::vector<Tensor> v{t.narrow(0, o, std::min(chunk_elems, t.numel() - o))};
@@ -169,6 +179,12 @@ class GradBucketReducer {
       staged_[b] = buf.to(*comm_dtype_);  // halve the bytes on the wire; accumulation stays fp32 in the arena
       buf = staged_[b];
     }
+    if (host_staged_) {
+      // several ranks rehearsing on one GPU over gloo: the bucket crosses gloo through host memory (this copy waits
+      // for the kernels that produced the bucket); finish() copies the reduced values back
+      staged_[b] = buf.to(at::kCPU);
+      buf = staged_[b];
+    }
     if (rccl_) {
       // ordered after the kernels that produced the bucket (everything enqueued on the compute stream so far)
       rccl_->fork();
@@ -191,7 +207,7 @@ class GradBucketReducer {
   bool average_;
   c10::optional<at::ScalarType> comm_dtype_;
   int nb_ = 0, world_ = 1, next_ = 0;
-  bool is_nccl_ = false, sync_ = true, active_ = false, force_ = false, launched_any_ = false;
+  bool is_nccl_ = false, host_staged_ = false, sync_ = true, active_ = false, force_ = false, launched_any_ = false;
   std::vector<Tensor> views_, staged_;
   std::vector<int64_t> ready_, order_;
   std::vector<c10::intrusive_ptr<c10d::Work>> works_;

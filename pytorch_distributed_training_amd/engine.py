@@ -201,6 +201,10 @@ class Engine:
     def reduce_mean(self, t: torch.Tensor) -> torch.Tensor:
         if self.num_processes == 1:
             return t
+        if t.is_cuda and dist.get_backend(self.pg) == "gloo":  # single-GPU rehearsal: cross gloo through the host
+            host = t.detach().cpu()
+            dist.all_reduce(host, group=self.pg)
+            return host.to(t.device) / self.num_processes
         t = t.clone()
         dist.all_reduce(t, group=self.pg)
         return t / self.num_processes
@@ -225,6 +229,11 @@ def gather(obj: Any, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
     t = t.contiguous()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # several ranks rehearsing on one GPU (gloo transport): GPU tensors cross gloo through the host
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, t.cpu(), group=group)
+        return torch.cat(parts, dim=0).to(t.device)
     out = torch.empty((dist.get_world_size(group) * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     return out

@@ -96,7 +96,15 @@ class FusedAdamW:
                 import torch.distributed as dist
 
                 C.grad_check(a.grad, self.scaler.state)
-                dist.all_reduce(self.scaler.state[2:3], op=dist.ReduceOp.MAX, group=overflow_group)
+                flag = self.scaler.state[2:3]
+                if dist.get_backend(overflow_group) == "gloo":
+                    # single-GPU rehearsal (ranks share the card, gloo transport): stage the flag through the host
+                    # ourselves, like every other GPU tensor that crosses gloo in this framework
+                    host = flag.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=overflow_group)
+                    flag.copy_(host)
+                else:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=overflow_group)
                 check = False
             C.adamw_step(a.master, self.m, self.v, a.grad, a.p16, self.lr, self.step_count, self.scaler.state,
                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.correct_bias, check)

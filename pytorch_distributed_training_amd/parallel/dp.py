@@ -160,7 +160,8 @@ class DataParallel(nn.Module):
 
         layout = ";".join(f"{n}:{o}:{k}" for n, (o, k) in sorted(self.arena.offsets.items()))
         mine = torch.tensor([self.arena.numel, len(self.arena.offsets), len(self.arena.bucket_bounds) - 1,
-                             zlib.crc32(layout.encode())], dtype=torch.int64, device=self.arena.device)
+                             zlib.crc32(layout.encode())], dtype=torch.int64,
+                            device=self.arena.device if dist.get_backend(self.pg) == "nccl" else "cpu")
         every = [torch.empty_like(mine) for _ in range(self.world_size)]
         dist.all_gather(every, mine, group=self.pg)
         bad = [r for r, t in enumerate(every) if not torch.equal(t, every[0])]
