@@ -166,6 +166,7 @@ def main() -> None:
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
                        "comm_backend": args.comm or os.environ.get("PDT_COMM", "c10d"),
+                       "gemm_persistent_mode": _persist_mode(),
                        "hip_graph": bool(args.graph),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,
                        "optimizer": "fused AdamW + dynamic loss scale",
@@ -173,7 +174,19 @@ def main() -> None:
         }))
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        _teardown()
+
+
+def _teardown() -> None:
+    """End of a multi-rank run: the result line is out; leave without running the interpreter's exit-time destructors
+    (communicator worker threads torn down in arbitrary order at exit can turn a finished run into a non-zero exit)."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    torch.cuda.synchronize()
+    multi = dist.get_world_size() > 1
+    dist.destroy_process_group()
+    if multi:  # (a 1-rank rehearsal exits normally: a profiler attached to it writes its output at exit)
+        os._exit(0)
 
 
 def bench_pipeline(args, world: int, comm) -> None:
@@ -242,7 +255,13 @@ def bench_pipeline(args, world: int, comm) -> None:
                        "optimizer": "fused AdamW + dynamic loss scale", "dropout": 0.1},
         }))
     dist.barrier()
-    dist.destroy_process_group()
+    _teardown()
+
+
+def _persist_mode() -> int:
+    from pytorch_distributed_training_amd.ops import native
+
+    return int(native().gemm_persistent_mode())
 
 
 def _pretty(model: str) -> str:

@@ -64,6 +64,13 @@ int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]   (out fp32; n multiple of 4)
 int pdt_splitk_reduce(const float* slab, int splits, int64_t n, float* out, int accumulate, void* stream);
 int pdt_gemm_max_splits(void);
+// Persistent launches of the 256x256 ping-pong kernel (256 workgroups walk the output tiles of a GEMM):
+// 0 never, 1 from 4 tiles per workgroup (default), 2 from 2 tiles per workgroup.  The default comes from the
+// PDT_GEMM_PERSIST environment variable; the setter overrides it (e.g. off while another stream's kernels -
+// gradient all-reduces, pipeline send/recv - share the CUs: one workgroup per tile lets them in at tile
+// granularity instead of at the end of a whole GEMM).
+int pdt_gemm_persist_mode(void);
+void pdt_gemm_set_persist_mode(int mode);
 // slabs a TN (weight-gradient) GEMM of this shape writes (g->splits > 0: that many); size C accordingly
 int pdt_gemm_tn_splits(int tile, const PdtGemm* g);
 // Number of K slices the dispatcher would like for this NT / NN problem (1 = none): small outputs (few tiles for

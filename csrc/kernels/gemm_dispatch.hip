@@ -4,6 +4,7 @@
 extern "C" int pdt_gemm_nt(int dtype, int tile, PdtGemm* g, void* stream);
 extern "C" int pdt_gemm_nn(int dtype, int tile, PdtGemm* g, void* stream);
 extern "C" int pdt_gemm_tn(int dtype, int tile, PdtGemm* g, void* stream);
+extern "C" int pdt_gemm_persist_mode(void);
 
 namespace pdt {
 constexpr int kMaxSplits = 32;
@@ -52,6 +53,16 @@ static void plan_tn(int tile, PdtGemm* g) {
 }  // namespace pdt
 
 extern "C" int pdt_gemm_max_splits(void) { return pdt::kMaxSplits; }
+
+static int g_persist_mode = -1;  // -1: not decided yet (read PDT_GEMM_PERSIST at first use)
+extern "C" int pdt_gemm_persist_mode(void) {
+  if (g_persist_mode < 0) {
+    const char* e = getenv("PDT_GEMM_PERSIST");
+    g_persist_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }
+  return g_persist_mode;
+}
+extern "C" void pdt_gemm_set_persist_mode(int mode) { g_persist_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
 // number of fp32 slabs a weight-gradient GEMM of this shape will write (what the caller must allocate)
 extern "C" int pdt_gemm_tn_splits(int tile, const PdtGemm* g) {

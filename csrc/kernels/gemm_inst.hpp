@@ -5,6 +5,8 @@
 #include <unordered_map>
 #include "gemm8.hpp"
 
+extern "C" int pdt_gemm_persist_mode(void);  // gemm_dispatch.hip
+
 namespace pdt {
 
 // Second kernel of a split-K forward / dgrad GEMM: C = epilogue(sum_s ws[s]) on 8 consecutive columns per thread,
@@ -98,6 +100,7 @@ static int launch_tile(PdtGemm& g, hipStream_t stream) {
 }
 
 constexpr int kPersistentWorkgroups = 256;  // one per CU (a workgroup owns all 160 KiB of LDS)
+constexpr int kPersistentMinTiles = 4 * kPersistentWorkgroups;
 
 // Ticket counters of persistent launches: 8 words (one per XCD) per stream - launches on one stream are ordered,
 // and the kernel leaves the counters re-armed (2 fixed tiles per workgroup already handed out) when it ends.
@@ -138,10 +141,15 @@ static int launch_pingpong(PdtGemm& g, hipStream_t stream) {
   }
   int grid = g.tiles_m * g.tiles_n * g.splits;
   // persistent launch (one workgroup per CU walks several output tiles, see Gemm8::run): needs every tile full, an
-  // even number of K-tiles, no K split and at least two tiles per workgroup; PDT_GEMM_PERSIST=0 turns it off
-  static const bool allow_persist = [] { const char* e = getenv("PDT_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
+  // even number of K-tiles, no K split and at least kPersistentMinTiles tiles (the kernel itself needs two per
+  // workgroup; with fewer than four the cross-tile prefetch has too few tile boundaries to pay for the ticket
+  // traffic, and the 8192-12288-token micro-batches that fall below it are the ones whose weight gradients run
+  // concurrently on a second stream); PDT_GEMM_PERSIST=0 turns it off, =2 lowers the bound to two tiles per workgroup
+  const int persist_mode = pdt_gemm_persist_mode();
+  const bool allow_persist = persist_mode != 0;
+  const int min_tiles = persist_mode == 2 ? 2 * kPersistentWorkgroups : kPersistentMinTiles;
   g.sync = nullptr;
-  if (allow_persist && g.epi != PDT_EPI_SLAB_F32 && grid >= 2 * kPersistentWorkgroups && g.M % 256 == 0 && g.N % 256 == 0 &&
+  if (allow_persist && g.epi != PDT_EPI_SLAB_F32 && grid >= min_tiles && g.M % 256 == 0 && g.N % 256 == 0 &&
       g.K % 128 == 0 && (g.sync = persistent_counters(stream)) != nullptr)
     grid = kPersistentWorkgroups;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, stream, g);

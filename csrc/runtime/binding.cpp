@@ -625,6 +625,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("site"), py::arg("dbias") = py::none());
   m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
         "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
+  m.def("set_gemm_persistent", [](int64_t mode) { pdt_gemm_set_persist_mode((int)mode); },
+        "persistent launches of the ping-pong GEMM: 0 never, 1 from 4 tiles per workgroup (default), 2 from 2");
+  m.def("gemm_persistent_mode", [] { return pdt_gemm_persist_mode(); });
   m.def("set_debug_sync", [](bool on) { g_debug_sync = on; },
         "drain the device after every native launch and report a fault at the op that caused it");
   m.def("debug_sync_count", [] { return g_debug_sync_count; });

@@ -116,9 +116,18 @@ class DeviceLoader:
         for b in it:
             queue.append(self._to_device(b))
             if len(queue) > self.prefetch:
-                moved, ev = queue.pop(0)
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                yield moved
+                yield self._hand_over(*queue.pop(0))
         for moved, ev in queue:
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            yield moved
+            yield self._hand_over(moved, ev)
+
+    def _hand_over(self, moved, ev):
+        """Order the consumer stream after the copy, and tell the caching allocator that the batch (allocated on the
+        copy stream) is read on the consumer stream: without that, its memory could be handed to a later prefetch copy
+        as soon as Python drops the batch, while kernels that read it are still queued."""
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        tensors = moved.values() if isinstance(moved, dict) else (moved if isinstance(moved, (list, tuple)) else [moved])
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+        return moved

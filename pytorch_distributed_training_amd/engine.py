@@ -99,6 +99,13 @@ class Engine:
             self.distributed_type = DistributedType.NO
         else:
             self.distributed_type = DistributedType.MULTI_GPU if on_gpu else DistributedType.MULTI_CPU
+        if self.native and dist.is_initialized() and dist.get_world_size() > 1 and "PDT_GEMM_PERSIST" not in os.environ:
+            # multi-rank runs share the CUs with the communication kernels of other streams (bucket all-reduces
+            # during backward, pipeline send/recv): the large GEMMs are launched one workgroup per output tile, so
+            # those kernels get in at tile granularity instead of waiting for a whole persistent GEMM
+            from .ops import native as _native
+
+            _native().set_gemm_persistent(0)
         self.seed = seed
         self.comm_dtype = comm_dtype
         # gradient all-reduce through c10d's "nccl" backend (default) or the framework's own RcclComm ("rccl")

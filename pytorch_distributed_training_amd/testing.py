@@ -3,6 +3,7 @@ self-launches with ``mp.spawn`` on 127.0.0.1, /root/reference/test_model_paralle
 collect each rank's return value."""
 from __future__ import annotations
 
+import gc
 import os
 import pickle
 import tempfile
@@ -29,6 +30,11 @@ def _entry(rank: int, world: int, port: int, fn: Callable, args: tuple, outdir: 
             pickle.dump(("err", traceback.format_exc()), f)
         raise
     finally:
+        # collect whatever still references the process group from C++ (a bucket reducer inside a reference cycle)
+        # BEFORE the group is destroyed: a group that outlives destroy_process_group() is torn down during
+        # interpreter exit, with its worker threads still running
+        res = None
+        gc.collect()
         if dist.is_initialized():
             dist.destroy_process_group()
 
