@@ -18,6 +18,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# dmabuf IPC (the only mode the host driver of these nodes supports) for RCCL / cross-process GPU memory:
+# must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import time
 

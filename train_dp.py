@@ -10,6 +10,10 @@ Defaults are the reference's: bert-large-cased, lr 2e-5, 3 epochs, batch 96 as 1
 point at a local GLUE/MRPC copy.
 """
 import os
+
+# dmabuf IPC (the only mode the host driver of these nodes supports) for RCCL / cross-process GPU memory:
+# must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

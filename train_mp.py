@@ -12,6 +12,10 @@ Unlike the reference (gloo, fp32 only, both ranks on the same two GPUs) mixed pr
 every rank owns one GPU.
 """
 import os
+
+# dmabuf IPC (the only mode the host driver of these nodes supports) for RCCL / cross-process GPU memory:
+# must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
