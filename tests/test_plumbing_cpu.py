@@ -386,3 +386,36 @@ def test_step_logger_evaluates_lazy_extra(tmp_path, capsys):
     rec = json.loads(path.read_text().strip())
     assert rec["comm_exposed_ms"] == 1.25 and "skipped" not in rec
     assert "comm-exposed 1.25 ms" in capsys.readouterr().out
+
+
+def test_comm_backend_choice_and_flag(monkeypatch):
+    """`--comm-backend rccl` / PDT_COMM select the framework's own RCCL communicator for the gradient path; CPU runs
+    keep the process group (gloo) whatever the choice; the watchdog's communicator poll is a no-op without one."""
+    from pytorch_distributed_training_amd.config import parse_config
+    from pytorch_distributed_training_amd.parallel.comm import backend_choice, create_rccl_comm
+    from pytorch_distributed_training_amd.utils.watchdog import poll_comm_errors
+
+    monkeypatch.delenv("PDT_COMM", raising=False)
+    assert backend_choice() == "c10d" and backend_choice("rccl") == "rccl"
+    monkeypatch.setenv("PDT_COMM", "rccl")
+    assert backend_choice() == "rccl" and backend_choice("c10d") == "c10d"
+    with pytest.raises(ValueError):
+        backend_choice("mpi")
+    assert parse_config(["--comm-backend", "rccl"]).comm_backend == "rccl"
+    assert parse_config([]).comm_backend is None
+    with pytest.raises(ValueError):
+        create_rccl_comm(device=torch.device("cpu"))
+    assert poll_comm_errors() is None
+
+
+def test_native_extension_exports_runtime_switches():
+    """The in-tree extension carries the communicator class and the run-time switches the engine uses."""
+    from pytorch_distributed_training_amd.ops import native
+
+    C = native()
+    assert hasattr(C, "RcclComm") and hasattr(C, "GradBucketReducer")
+    before = C.gemm_persistent_mode()
+    C.set_gemm_persistent(0)
+    assert C.gemm_persistent_mode() == 0
+    C.set_gemm_persistent(before)
+    assert C.gemm_persistent_mode() == before

@@ -65,3 +65,31 @@ def test_local_mrpc_reader(tmp_path, vocab_file):
     assert ex["labels"] == 1 and ex["input_ids"][0] == 2 and ex["input_ids"][-1] == 3
     assert len(ex["input_ids"]) == len(ex["token_type_ids"]) == len(ex["attention_mask"])
     assert ex["token_type_ids"][-1] == 1 and ex["token_type_ids"][0] == 0
+
+
+def test_local_mrpc_reader_parquet_and_arrow_equal_tsv(tmp_path, vocab_file):
+    """The hub's storage formats (Parquet files; the Arrow stream files of a `datasets` cache) give the same
+    tokenized examples as the classic GLUE TSV files."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    s1 = ["The quick brown fox .", "the lazy dog"]
+    s2 = ["the fox jumps .", "Amrozi accused his brother"]
+    y = [1, 0]
+    tsv, par, arr = tmp_path / "tsv", tmp_path / "parquet", tmp_path / "arrow"
+    for d in (tsv, par, arr):
+        d.mkdir()
+    rows = ["Quality\t#1 ID\t#2 ID\t#1 String\t#2 String"] + [f"{y[i]}\t{i}\t{i}\t{s1[i]}\t{s2[i]}" for i in range(2)]
+    for name in ("train.tsv", "dev.tsv"):
+        (tsv / name).write_text("\n".join(rows) + "\n", encoding="utf-8")
+    table = pa.table({"sentence1": s1, "sentence2": s2, "label": y, "idx": [0, 1]})
+    pq.write_table(table, str(par / "train-00000-of-00001.parquet"))
+    pq.write_table(table, str(par / "validation-00000-of-00001.parquet"))
+    for name in ("glue-train.arrow", "glue-validation.arrow"):
+        with pa.OSFile(str(arr / name), "wb") as sink, pa.ipc.new_stream(sink, table.schema) as w:
+            w.write_table(table)
+    ref_train, ref_dev = load_mrpc_tsv(str(tsv), vocab_file, max_length=16)
+    for d in (par, arr):
+        train, dev = load_mrpc_tsv(str(d), vocab_file, max_length=16)
+        assert [train[i] for i in range(2)] == [ref_train[i] for i in range(2)]
+        assert [dev[i] for i in range(2)] == [ref_dev[i] for i in range(2)]
