@@ -80,6 +80,11 @@ def init_distributed(cpu: bool = False, backend: Optional[str] = None, timeout_s
 
 
 def shutdown() -> None:
+    """Destroy the default process group.  Objects that hold the group from C++ (bucket reducers) are collected
+    first: a group that outlives this call is torn down at interpreter exit, with its worker threads still running."""
+    import gc
+
+    gc.collect()
     if dist.is_initialized():
         dist.destroy_process_group()
 

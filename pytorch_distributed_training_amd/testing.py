@@ -6,6 +6,7 @@ from __future__ import annotations
 import gc
 import os
 import pickle
+import sys
 import tempfile
 import traceback
 from typing import Any, Callable, List
@@ -20,23 +21,32 @@ from .launch import DistEnv, find_free_port
 def _entry(rank: int, world: int, port: int, fn: Callable, args: tuple, outdir: str, backend: str) -> None:
     DistEnv(rank, rank, world, "127.0.0.1", port).export()
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(2, world)))
+    code = 0
     try:
         dist.init_process_group(backend, rank=rank, world_size=world)
         res = fn(rank, world, *args)
         with open(os.path.join(outdir, f"r{rank}.pkl"), "wb") as f:
             pickle.dump(("ok", res), f)
-    except BaseException:  # noqa: BLE001 - report the traceback to the parent
+    except BaseException:  # noqa: BLE001 - the traceback goes to the parent through the result file
         with open(os.path.join(outdir, f"r{rank}.pkl"), "wb") as f:
             pickle.dump(("err", traceback.format_exc()), f)
-        raise
+        traceback.print_exc()
+        code = 1
     finally:
-        # collect whatever still references the process group from C++ (a bucket reducer inside a reference cycle)
-        # BEFORE the group is destroyed: a group that outlives destroy_process_group() is torn down during
-        # interpreter exit, with its worker threads still running
+        # Whatever still references the process group from C++ (a bucket reducer inside a reference cycle, or frames
+        # kept alive by a traceback) would keep the group alive past destroy_process_group() until interpreter exit,
+        # where its worker threads are torn down in arbitrary order ("terminate called without an active exception").
+        # The result is on disk: collect, destroy the group, and leave without exit-time destructors.
         res = None
         gc.collect()
-        if dist.is_initialized():
-            dist.destroy_process_group()
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
 
 
 def run_distributed(fn: Callable, world: int = 2, args: tuple = (), backend: str = "gloo") -> List[Any]:
