@@ -62,7 +62,8 @@ class GradBucketReducer {
     }
     world_ = rccl_ ? (int)rccl_->size() : pg_->getSize();
     is_nccl_ = rccl_ ? true : pg_->getBackendName() == "nccl";
-    host_staged_ = !rccl_ && !is_nccl_ && arena_.is_cuda();
+    // (only when the backend positively is gloo: any other group gets the GPU tensor as it is)
+    host_staged_ = !rccl_ && arena_.is_cuda() && pg_->getBackendName() == "gloo";
     if (rccl_) TORCH_CHECK(arena_.is_cuda() && arena_.get_device() == rccl_->device(), "arena is not on the communicator's GPU");
     // PDT_FORCE_COLLECTIVES=1 issues the collectives even in a 1-rank group (exercises the RCCL call path on
     // a single-GPU test box)
