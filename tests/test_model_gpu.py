@@ -294,3 +294,20 @@ def test_bench_contract_json_line():
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3 / 1000)) / d["value"] < 1e-2
     for key in ("model", "global_batch", "seq_len", "parallelism"):
         assert key in d["config"], key
+
+
+def test_data_parallel_recipe_end_to_end_single_gpu(tmp_path):
+    """The DP recipe on the GPU the way train_dp.py runs it: dynamically padded batches through the prefetching
+    DeviceLoader, native fp16 training without a host sync per step, evaluation, checkpoint at the end of every
+    epoch, and a second invocation that resumes from it (nothing left to train)."""
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.recipes import run_data_parallel
+
+    cfg = TrainConfig(model="bert-tiny", fp16=True, train_examples=256, eval_examples=64, num_epochs=2, batch_size=32,
+                      max_gpu_batch_size=32, lr=1e-3, num_warmup_steps=2, log_every=1000, seed=11, init_scale=1024.0,
+                      output_dir=str(tmp_path))
+    out = run_data_parallel(cfg)
+    assert out["optimizer_steps"] == 16
+    assert 0.0 <= out["accuracy"] <= 1.0 and 0.0 <= out["f1"] <= 1.0
+    again = run_data_parallel(cfg)
+    assert again["optimizer_steps"] == 16  # resumed at the end of the last epoch: no further steps
