@@ -66,8 +66,10 @@ RcclComm::RcclComm(const std::string& unique_id, int64_t rank, int64_t world, in
   int lo = 0, hi = 0;  // (numerically lowest value = highest priority)
   PDT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   PDT_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
-  PDT_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-  PDT_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  for (int i = 0; i < kEvents; ++i) {
+    PDT_HIP(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
+    PDT_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+  }
   PDT_NCCL(ncclCommInitRank(&comm_, (int)world, id, (int)rank));
   barrier_word_ = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(at::kCUDA, (c10::DeviceIndex)device));
 }
@@ -83,8 +85,10 @@ void RcclComm::close() {
   PDT_HIP(hipStreamSynchronize(stream_));
   PDT_NCCL(ncclCommDestroy(comm_));
   comm_ = nullptr;
-  (void)hipEventDestroy(ev_fork_);
-  (void)hipEventDestroy(ev_join_);
+  for (int i = 0; i < kEvents; ++i) {
+    (void)hipEventDestroy(ev_fork_[i]);
+    (void)hipEventDestroy(ev_join_[i]);
+  }
   (void)hipStreamDestroy(stream_);
   stream_ = nullptr;
 }
@@ -97,14 +101,16 @@ void RcclComm::check_tensor(const at::Tensor& t) const {
 
 void RcclComm::fork() {
   TORCH_CHECK(comm_, "communicator is closed");
-  PDT_HIP(hipEventRecord(ev_fork_, current_stream()));
-  PDT_HIP(hipStreamWaitEvent(stream_, ev_fork_, 0));
+  hipEvent_t ev = ev_fork_[n_fork_++ % kEvents];
+  PDT_HIP(hipEventRecord(ev, current_stream()));
+  PDT_HIP(hipStreamWaitEvent(stream_, ev, 0));
 }
 
 void RcclComm::join() {
   TORCH_CHECK(comm_, "communicator is closed");
-  PDT_HIP(hipEventRecord(ev_join_, stream_));
-  PDT_HIP(hipStreamWaitEvent(current_stream(), ev_join_, 0));
+  hipEvent_t ev = ev_join_[n_join_++ % kEvents];
+  PDT_HIP(hipEventRecord(ev, stream_));
+  PDT_HIP(hipStreamWaitEvent(current_stream(), ev, 0));
 }
 
 void RcclComm::all_reduce_async(const at::Tensor& t, bool average) {

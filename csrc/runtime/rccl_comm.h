@@ -71,8 +71,12 @@ class RcclComm {
   void check_tensor(const at::Tensor& t) const;
   ncclComm* comm_ = nullptr;
   ihipStream_t* stream_ = nullptr;
-  ihipEvent_t* ev_fork_ = nullptr;
-  ihipEvent_t* ev_join_ = nullptr;
+  // rings of events: a fork / join never re-records an event that an earlier, possibly still pending, stream wait
+  // refers to (one backward pass forks once per bucket)
+  static constexpr int kEvents = 64;
+  ihipEvent_t* ev_fork_[kEvents] = {};
+  ihipEvent_t* ev_join_[kEvents] = {};
+  uint64_t n_fork_ = 0, n_join_ = 0;
   at::Tensor barrier_word_;
   int64_t rank_ = 0, world_ = 1, device_ = 0, launches_ = 0, bytes_ = 0;
 };
