@@ -2,8 +2,8 @@
 # 1/2/4/8-GPU weak-scaling sweep of the headline benchmark on ONE node (one process per GPU, RCCL over xGMI).
 # Prints one JSON line per GPU count and the scaling efficiency relative to the 1-GPU run.
 #   bash bench/scale_sweep.sh [steps] [warmup] [extra bench.py flags...]
-# A 2-stage pipeline x data-parallel run of the same model (loss curve comparison) follows when
-# PDT_SWEEP_MP=1:  python train_mp.py --fp16=True --max-steps 20 on all visible GPUs.
+# With PDT_SWEEP_MP=1 the data-parallel x 2-stage-pipeline layout follows on all visible GPUs: bench.py --pp 2
+# (BERT-large seq 128 fp16, RoBERTa-large seq 512 bf16) and python train_mp.py --fp16=True --max-steps 20.
 set -euo pipefail
 cd "$(dirname "$0")/.."
 STEPS=${1:-20}; WARMUP=${2:-5}; shift $(( $# > 2 ? 2 : $# )) || true
@@ -24,5 +24,12 @@ for n in 1 2 4 8; do
   python -c 'import sys; n,v,b=int(sys.argv[1]),float(sys.argv[2]),float(sys.argv[3]); print(f"# {n} GPU(s): {v:.1f} samples/s, scaling efficiency {100*v/(n*b):.1f} %")' "$n" "$v" "$base"
 done
 if [ "${PDT_SWEEP_MP:-0}" = "1" ] && [ "$NGPU" -ge 2 ]; then
+  # data parallel x 2-stage pipeline on all GPUs (GPU pairs form replicas): throughput of the same model, then the
+  # seq-512 RoBERTa-large configuration, then the training recipe (loss curve)
+  n=$(( NGPU / 2 * 2 ))
+  for extra in "" "--model roberta-large --seq-len 512 --dtype bf16"; do
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port 29650 \
+      bench.py --gpus "$n" --pp 2 --micro-batches 8 --steps "$STEPS" --warmup "$WARMUP" $extra | tail -1
+  done
   python train_mp.py --fp16=True --max-steps 20 --log-every 1
 fi
