@@ -96,14 +96,16 @@ int pdt_colsum_partial(int dtype, const void* x, int rows, int ncols, int ld, fl
 
 // ---- Embeddings -----------------------------------------------------------------------------------
 // y = dropout(LN(word[ids] + pos[pos_ids] + type[type_ids]));  pre = the LN input (saved for backward)
+// (V, P, R = rows of the word / position / token-type tables: an index outside its table is clamped into it, so
+// a corrupt or mismatched id tensor gives wrong embeddings, not a GPU memory fault)
 int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
                   const void* inputs_embeds, const void* word, const void* pos, const void* type,
                   const void* gamma, const void* beta, void* pre, void* y, float* stats, int tokens, int H,
-                  float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+                  int V, int P, int R, float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
 // scatter-add rows of d (16-bit [tokens,H]) into the fp32 tables gw[ids] (skipping `pad_id`) and
-// gp[pos_ids] with fp32 atomics; either table may be null
+// gp[pos_ids] with fp32 atomics; either table may be null; rows outside [0,V) / [0,P) are skipped
 int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw, float* gp,
-                      int tokens, int H, int64_t pad_id, void* stream);
+                      int tokens, int H, int V, int P, int64_t pad_id, void* stream);
 // token-type table gradient (R <= 4 rows) as deterministic masked column partial sums partial[nblk][R][H]
 // (finish with pdt_colsum_finish, nseg = R)
 int pdt_embed_type_partial(int dtype, const void* d, const int64_t* type_ids, float* partial, int* nblk, int tokens,

@@ -12,15 +12,18 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const T* __restrict__ word, const T* __restrict__ pos,
                                                         const T* __restrict__ type, const T* __restrict__ gamma,
                                                         const T* __restrict__ beta, T* __restrict__ pre, T* __restrict__ y,
-                                                        float* __restrict__ stats, int tokens, int H, float eps,
-                                                        float drop_scale, uint32_t drop_thr, RngArgs rng) {
+                                                        float* __restrict__ stats, int tokens, int H, int V, int P,
+                                                        int R, float eps, float drop_scale, uint32_t drop_thr,
+                                                        RngArgs rng) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= tokens) return;
   const int nchunk = H >> 3;
-  const T* wrow = inputs_embeds ? inputs_embeds + (size_t)tok * H : word + (size_t)ids[tok] * H;
-  const T* prow = pos + (size_t)pos_ids[tok] * H;
-  const T* trow = type + (size_t)type_ids[tok] * H;
+  // indices come from user data: clamp them into their tables (a bad id must not become a wild address)
+  auto clampi = [](int64_t v, int n) { return (size_t)(v < 0 ? 0 : (v >= n ? n - 1 : v)); };
+  const T* wrow = inputs_embeds ? inputs_embeds + (size_t)tok * H : word + clampi(ids[tok], V) * H;
+  const T* prow = pos + clampi(pos_ids[tok], P) * H;
+  const T* trow = type + clampi(type_ids[tok], R) * H;
   float v[EMB_MAX_CHUNKS][8];
   float sum = 0.f;
 #pragma unroll
@@ -78,13 +81,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ d, const int64_t* __restrict__ ids,
                                                             const int64_t* __restrict__ pos_ids, float* __restrict__ gw,
-                                                            float* __restrict__ gp, int tokens, int H, int64_t pad_id) {
+                                                            float* __restrict__ gp, int tokens, int H, int V, int P,
+                                                            int64_t pad_id) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= tokens) return;
   const int64_t id = ids ? ids[tok] : -1;
-  float* wrow = (gw && ids && id != pad_id) ? gw + (size_t)id * H : nullptr;
-  float* prow = gp ? gp + (size_t)pos_ids[tok] * H : nullptr;
+  float* wrow = (gw && ids && id != pad_id && id >= 0 && id < V) ? gw + (size_t)id * H : nullptr;
+  const int64_t ps = gp ? pos_ids[tok] : -1;
+  float* prow = (gp && ps >= 0 && ps < P) ? gp + (size_t)ps * H : nullptr;
   for (int c = lane; c < H; c += 64) {
     const float v = Half16<T>::to_f(reinterpret_cast<const short*>(d)[(size_t)tok * H + c]);
     if (wrow) atomicAdd(wrow + c, v);
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256) void embed_type_partial_kernel(const T* __rest
   for (int t = r0; t < r1; ++t) {
     float v[8];
     unpack8<T>(*reinterpret_cast<const short8*>(d + (size_t)t * H + col), v);
-    const int ty = (int)type_ids[t];
+    const int64_t tr = type_ids[t];
+    const int ty = tr < 0 ? 0 : (tr >= R ? R - 1 : (int)tr);  // (clamped like the forward lookup)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (r == ty)
@@ -127,29 +133,30 @@ using namespace pdt;
 extern "C" int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
                              const void* inputs_embeds, const void* word, const void* pos, const void* type,
                              const void* gamma, const void* beta, void* pre, void* y, float* stats, int tokens, int H,
-                             float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
-  if ((H & 7) || H > EMB_MAX_CHUNKS * 512 || tokens <= 0) return -3;
+                             int V, int P, int R, float eps, float drop_scale, uint32_t drop_thr, PdtRng rng,
+                             void* stream) {
+  if ((H & 7) || H > EMB_MAX_CHUNKS * 512 || tokens <= 0 || V <= 0 || P <= 0 || R <= 0) return -3;
   if (!ids && !inputs_embeds) return -2;
   const dim3 grid((tokens + 3) / 4), block(256);
 #define PDT_GO(TT)                                                                                                   \
   hipLaunchKernelGGL(embed_fwd_kernel<TT>, grid, block, 0, (hipStream_t)stream, ids, pos_ids, type_ids,               \
                      (const TT*)inputs_embeds, (const TT*)word, (const TT*)pos, (const TT*)type, (const TT*)gamma,    \
-                     (const TT*)beta, (TT*)pre, (TT*)y, stats, tokens, H, eps, drop_scale, drop_thr, rng)
+                     (const TT*)beta, (TT*)pre, (TT*)y, stats, tokens, H, V, P, R, eps, drop_scale, drop_thr, rng)
   if (dtype == PDT_F16) PDT_GO(_Float16); else PDT_GO(__bf16);
 #undef PDT_GO
   return (int)hipGetLastError();
 }
 
 extern "C" int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw,
-                                 float* gp, int tokens, int H, int64_t pad_id, void* stream) {
-  if (tokens <= 0) return -3;
+                                 float* gp, int tokens, int H, int V, int P, int64_t pad_id, void* stream) {
+  if (tokens <= 0 || (gw && V <= 0) || (gp && P <= 0)) return -3;
   const dim3 grid((tokens + 3) / 4), block(256);
   if (dtype == PDT_F16)
     hipLaunchKernelGGL(embed_scatter_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16*)d, ids,
-                       pos_ids, gw, gp, tokens, H, pad_id);
+                       pos_ids, gw, gp, tokens, H, V, P, pad_id);
   else
     hipLaunchKernelGGL(embed_scatter_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)d, ids,
-                       pos_ids, gw, gp, tokens, H, pad_id);
+                       pos_ids, gw, gp, tokens, H, V, P, pad_id);
   return (int)hipGetLastError();
 }
 

@@ -366,7 +366,8 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
   if (inputs_embeds.has_value()) { chk16(*inputs_embeds, "inputs_embeds"); iep = inputs_embeds->data_ptr(); }
   check(pdt_embed_fwd(dt_code(word), idp, pos_ids.data_ptr<int64_t>(), type_ids.data_ptr<int64_t>(), iep,
                       word.data_ptr(), pos.data_ptr(), type.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                      pre.data_ptr(), y.data_ptr(), stats.data_ptr<float>(), tokens, H, (float)eps, keep_scale(p),
+                      pre.data_ptr(), y.data_ptr(), stats.data_ptr<float>(), tokens, H, (int)word.size(0), (int)pos.size(0),
+                      (int)type.size(0), (float)eps, keep_scale(p),
                       thr16(p), make_rng(rng_state, micro, site), cur_stream()), "embed_fwd");
   return {y, pre, stats};
 }
@@ -394,7 +395,8 @@ Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stat
   }
   check(pdt_embed_scatter(dt_code(pre), l.dx.data_ptr(), ids.has_value() ? ids->data_ptr<int64_t>() : nullptr,
                           pos_ids.data_ptr<int64_t>(), ids.has_value() ? gr[0].data_ptr<float>() : nullptr,
-                          gr[1].data_ptr<float>(), tokens, H, pad_id, cur_stream()), "embed_scatter");
+                          gr[1].data_ptr<float>(), tokens, H, (int)gr[0].size(0), (int)gr[1].size(0), pad_id, cur_stream()),
+        "embed_scatter");
   const int R = (int)gr[2].size(0);
   Tensor partial = at::empty({256, R, H}, stats.options());
   int nblk = 0;

@@ -589,3 +589,36 @@ def test_kernels_at_131072_tokens():
     assert rel_err(dqkv[-nb * S:], qf.grad) < 6e-3
     if dbias is not None:
         torch.testing.assert_close(dbias, dqkv.float().sum(0), rtol=5e-3, atol=0.5)
+
+
+def test_embedding_indices_outside_their_tables_are_clamped_not_dereferenced():
+    """Token / position / token-type ids come from user data.  An id outside its table (a tokenizer with a larger
+    vocabulary, a corrupted batch) must not become a wild address: the forward lookup clamps it into the table, the
+    gradient scatter skips it."""
+    torch.manual_seed(14)
+    dtype = torch.float16
+    V, P, R, H, T = 300, 64, 2, 128, 96
+    word = (torch.randn(V, H, device="cuda") * 0.5).to(dtype)
+    pos = (torch.randn(P, H, device="cuda") * 0.5).to(dtype)
+    typ = (torch.randn(R, H, device="cuda") * 0.5).to(dtype)
+    g = torch.ones(H, device="cuda", dtype=dtype)
+    b = torch.zeros(H, device="cuda", dtype=dtype)
+    ids = torch.randint(1, V, (T,), device="cuda")
+    pids = torch.arange(T, device="cuda") % P
+    tids = torch.randint(0, R, (T,), device="cuda")
+    bad_ids, bad_p, bad_t = ids.clone(), pids.clone(), tids.clone()
+    bad_ids[3], bad_ids[10], bad_p[5], bad_t[7], bad_t[8] = V + 5, -4, P + 100, 28995, -1
+    st = rng_state()
+    y_bad, pre_bad, stats_bad = C().embed_forward(bad_ids, bad_p, bad_t, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+    y_ref, _, _ = C().embed_forward(bad_ids.clamp(0, V - 1), bad_p.clamp(0, P - 1), bad_t.clamp(0, R - 1), None, word,
+                                    pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+    assert torch.equal(y_bad, y_ref)
+    f32 = dict(device="cuda", dtype=torch.float32)
+    grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
+             torch.zeros(H, **f32)]
+    dy = torch.randn(T, H, device="cuda").to(dtype)
+    C().embed_backward(dy, pre_bad, stats_bad, bad_ids, bad_p, bad_t, g, grads, st, 0.0, 0, 0, 0, False)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(x).all() for x in grads)
+    # rows of valid tokens received their gradient; nothing was written for the out-of-table word / position rows
+    assert grads[0][ids[0]].abs().sum() > 0 and grads[1][pids[0]].abs().sum() > 0
