@@ -11,3 +11,11 @@ for grp in "gemm_nt" "gemm_nn" "gemm_tn or gemm_dropout" "layernorm" "attention"
   echo "group [$grp] exit=$rc: $(tail -1 gpurun_out/kt_${name}.log)"
   if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping: abnormal exit"; exit $rc; fi
 done
+# the remaining GPU test files, one process each (model path, prefetching loader, multi-process rehearsals)
+for f in tests/test_model_gpu.py tests/test_loader_gpu.py tests/test_distributed_gpu.py; do
+  name=$(basename "$f" .py)
+  timeout -k 10 600 python -u -m pytest "$f" -q --timeout 300 --timeout-method thread > "gpurun_out/kt_${name}.log" 2>&1
+  rc=$?
+  echo "file [$f] exit=$rc: $(tail -1 gpurun_out/kt_${name}.log)"
+  if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping: abnormal exit"; exit $rc; fi
+done
