@@ -36,6 +36,9 @@ from pytorch_distributed_training_amd.models.bert import build_model  # noqa: E4
 from pytorch_distributed_training_amd.optim import AdamW, get_linear_schedule_with_warmup  # noqa: E402
 
 
+REFERENCE_STACK_1GPU = 2014.0  # samples/s, bert-large-cased, seq 128, batch 1024, fp16 AMP, one MI355X
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +169,12 @@ def main() -> None:
             "final_loss": float(loss.item()) * args.accum,
             "tokens_per_s": round(value * args.seq_len, 1),
             "comm_exposed_ms_per_step": exposed,
+            # not a published number (the reference has none, hence vs_baseline = null): the reference's software
+            # stack (transformers + torch AMP, SDPA attention) measured on one MI355X at this configuration with
+            # bench/eager_baseline.py (last lines of profiles/perf_table_mi355x.jsonl: 2014 and 2018 samples/s in two runs)
+            "vs_reference_stack_1gpu": (round(value / REFERENCE_STACK_1GPU, 3)
+                                        if (world == 1 and args.model == "bert-large-cased" and args.seq_len == 128
+                                            and args.batch == 1024) else None),
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
