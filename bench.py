@@ -6,12 +6,19 @@ The configuration is the reference's data-parallel launch (bert-large-cased, MRP
 /root/reference/test_data_parallelism.py:69-150,174) on synthetic token batches of seq 128 with random-init
 weights.  Every timed step is a full optimizer step: forward, backward (with the bucketed gradient
 all-reduce when N > 1), fused AdamW with dynamic loss scaling, LR schedule, zero_grad.  The per-GPU batch
-defaults to 256 samples in one micro-batch (weak scaling: it stays fixed as N grows); the reference's literal
-"96 = 12 x 8" accumulation layout is `--batch 96 --accum 12`.
+defaults to 131072 tokens (1024 samples of 128 tokens) in one micro-batch (weak scaling: it stays fixed as N
+grows); the reference's literal "96 = 12 x 8" accumulation layout is `--batch 96 --accum 12`.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W        # no launcher environment: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Started without a launcher environment and with ``--gpus N`` > 1, the script launches ``torch.distributed.run``
+with N fresh rank processes as a child (the way the reference's model-parallel script spawns its own ranks,
+/root/reference/test_model_parallelism.py:331-335) before anything has touched a GPU, and exits with the child's
+status; rank 0 prints the one JSON line either way.  Multi-rank runs verify after the warm-up steps and again
+after the timed steps that all data-parallel replicas hold bit-identical parameters and fail loudly otherwise.
 """
 from __future__ import annotations
 
@@ -73,6 +80,8 @@ def main() -> None:
     if args.batch is None:
         args.batch = max(1, 131072 // args.seq_len)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -133,6 +142,7 @@ def main() -> None:
     for i in range(max(args.warmup, 3 if args.graph else 0)):
         step(i)
     _fence(eng)
+    _check_replicas(model)  # (outside the timed region)
     # two events per backward around the waits for the bucket collectives: reports how much of the gradient
     # communication backward did not hide (diagnostic only, nothing is synchronised inside the timed region)
     timed_dp = hasattr(model, "comm_exposed_ms")
@@ -150,6 +160,7 @@ def main() -> None:
     dt = float(t.item())
     exposed = model.comm_exposed_ms() if timed_dp else None
     exposed = round(exposed, 3) if exposed is not None else None
+    replicas_equal = _check_replicas(model)
     global_batch = args.batch * world
     value = global_batch * args.steps / dt
     if eng.is_main_process:
@@ -169,6 +180,8 @@ def main() -> None:
             "final_loss": float(loss.item()) * args.accum,
             "tokens_per_s": round(value * args.seq_len, 1),
             "comm_exposed_ms_per_step": exposed,
+            "rccl_ranks": _rccl_ranks(eng.pg),
+            "replicas_bit_equal": replicas_equal,
             # not a published number (the reference has none, hence vs_baseline = null): the reference's software
             # stack (transformers + torch AMP, SDPA attention) measured on one MI355X at this configuration with
             # bench/eager_baseline.py (last lines of profiles/perf_table_mi355x.jsonl: 2014 and 2018 samples/s in two runs)
@@ -188,6 +201,36 @@ def main() -> None:
     if dist.is_initialized():
         dist.barrier()
         _teardown()
+
+
+def _self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: run N fresh rank processes under torch.distributed.run as a
+    child of this process (which has not touched a GPU and never will) and hand its exit status back.  With fewer
+    GPUs than ranks (a rehearsal on a one-GPU box) the ranks share the card over gloo, see launch.default_backend."""
+    import subprocess
+
+    from pytorch_distributed_training_amd.launch import find_free_port
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(find_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd).returncode
+
+
+def _rccl_ranks(group=None) -> int:
+    """Ranks of the gradient group that talk RCCL ("nccl" backend on ROCm); 0 for single-process and gloo runs."""
+    if not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return 0
+    return dist.get_world_size(group)
+
+
+def _check_replicas(model):
+    """True after every data-parallel replica was verified to hold bit-identical parameters (raises otherwise);
+    None when the model is not data parallel."""
+    if not hasattr(model, "check_replicas"):
+        return None
+    model.check_replicas()
+    return True
 
 
 def _teardown() -> None:
@@ -239,12 +282,19 @@ def bench_pipeline(args, world: int, comm) -> None:
         step(i)
     dist.barrier()
     torch.cuda.synchronize()
+    _check_replicas(stage)
+    timed_dp = hasattr(stage, "comm_exposed_ms")
+    if timed_dp:
+        stage.measure_exposed = True
+        stage.comm_exposed_ms()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed = stage.comm_exposed_ms() if timed_dp else None
+    replicas_equal = _check_replicas(stage)
     t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -260,6 +310,8 @@ def bench_pipeline(args, world: int, comm) -> None:
             "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
             "final_loss": box[0], "tokens_per_s": round(value * args.seq_len, 1),
+            "comm_exposed_ms_per_step": round(exposed, 3) if exposed is not None else None,
+            "rccl_ranks": _rccl_ranks(None), "replicas_bit_equal": replicas_equal,
             "config": {"model": args.model, "global_batch": global_batch, "per_replica_batch": replica_batch,
                        "micro_batches": args.micro_batches, "seq_len": args.seq_len,
                        "parallelism": f"dp{mesh.dp} x pp2 (1F1B)", "backend": dist.get_backend(),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 namespace py = pybind11;
@@ -63,9 +64,20 @@ RcclComm::RcclComm(const std::string& unique_id, int64_t rank, int64_t world, in
   ncclUniqueId id;
   std::memcpy(&id, unique_id.data(), sizeof(id));
   PDT_HIP(hipSetDevice((int)device));
-  int lo = 0, hi = 0;  // (numerically lowest value = highest priority)
-  PDT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  PDT_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+  // The communication stream has NORMAL priority, like the compute stream.  Measured with bench/dev/rccl_stall.cpp
+  // on ROCm 7.0 and 7.2 (one process per variant): once an RCCL communicator exists in the process, a chain of
+  // record / wait pairs between the null stream and a stream created with the greatest priority never drains
+  // (64 rounds enqueue in 2 ms and are still pending 15 s later; with or without an ncclAllReduce in between),
+  // while the same chain on a normal-priority stream - or against an explicitly created compute stream - drains in
+  // 2 ms.  PyTorch computes on the null stream, so the elevated priority is opt-in (PDT_COMM_STREAM_PRIORITY=high).
+  const char* prio = std::getenv("PDT_COMM_STREAM_PRIORITY");
+  if (prio && std::strcmp(prio, "high") == 0) {
+    int least = 0, greatest = 0;
+    PDT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    PDT_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
+  } else {
+    PDT_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  }
   for (int i = 0; i < kEvents; ++i) {
     PDT_HIP(hipEventCreateWithFlags(&ev_fork_[i], hipEventDisableTiming));
     PDT_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
@@ -185,6 +197,13 @@ void RcclComm::synchronize() {
   PDT_HIP(hipStreamSynchronize(stream_));
 }
 
+int64_t RcclComm::comm_count() const {
+  TORCH_CHECK(comm_, "communicator is closed");
+  int n = 0;
+  PDT_NCCL(ncclCommCount(comm_, &n));
+  return n;
+}
+
 void RcclComm::check_async_error() {
   TORCH_CHECK(comm_, "communicator is closed");
   ncclResult_t async = ncclSuccess;
@@ -220,6 +239,7 @@ void bind_rccl_comm(py::module_& m) {
       .def("barrier", &RcclComm::barrier, py::call_guard<py::gil_scoped_release>())
       .def("synchronize", &RcclComm::synchronize, py::call_guard<py::gil_scoped_release>())
       .def("check_async_error", &RcclComm::check_async_error)
+      .def("comm_count", &RcclComm::comm_count, "ranks of the communicator as RCCL itself reports them (ncclCommCount)")
       .def("close", &RcclComm::close, py::call_guard<py::gil_scoped_release>())
       .def("collectives", &RcclComm::collectives)
       .def("bytes", &RcclComm::bytes);

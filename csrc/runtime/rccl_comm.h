@@ -1,7 +1,7 @@
 // RcclComm: a communicator of this framework's own, straight on the RCCL C API.
 //
-// One RcclComm = one ncclComm_t of one process-per-GPU rank + one HIP stream that belongs to it (highest
-// priority, non-blocking) + the two events that order that stream against the compute stream.  Collectives
+// One RcclComm = one ncclComm_t of one process-per-GPU rank + one HIP stream that belongs to it (non-blocking,
+// normal priority - see the constructor) + the events that order that stream against the compute stream.  Collectives
 // never block the host: `fork()` makes the communication stream wait for everything enqueued so far on the
 // current compute stream, the collective is enqueued on the communication stream, `join()` makes the compute
 // stream wait for everything enqueued on the communication stream.  The bucket reducer forks per bucket and
@@ -60,6 +60,7 @@ class RcclComm {
   }
   void barrier();  // 1-element all-reduce + host wait for the communication stream
 
+  int64_t comm_count() const;  // ncclCommCount
   // raises if RCCL has recorded an asynchronous error on this communicator (the watchdog's poll)
   void check_async_error();
   void synchronize();  // host wait for the communication stream

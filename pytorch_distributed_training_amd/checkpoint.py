@@ -9,9 +9,9 @@ never saves anything, so an elastic restart recomputes from scratch.  Here:
   ``transformers.BertForSequenceClassification`` and vice versa.  Legacy ``bert.embeddings.position_ids``
   buffers and ``LayerNorm.gamma/beta`` spellings are tolerated on load.
 * :func:`save_training_state` / :func:`load_training_state` add the sidecar needed to resume exactly:
-  optimizer moments, step count, loss scale, LR-schedule position, epoch / in-epoch offset, RNG counters.
-  A pipeline stage saves only its own layer range (``stage{K}`` suffix); rank 0 of each data-parallel group
-  writes.
+  optimizer moments, step count, loss scale, LR-schedule position, epoch / in-epoch batch offset, RNG counters.
+  A checkpoint is a step-numbered subdirectory published atomically through ``latest.json``.  A model-parallel
+  rank saves only its own part (``stage{K}`` suffix); rank 0 of each data-parallel group writes.
 """
 from __future__ import annotations
 
@@ -39,10 +39,10 @@ def _hf_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
     return {k: v.detach().to("cpu", copy=True).contiguous() for k, v in sd.items() if not k.startswith("_")}
 
 
-def save_pretrained(model: nn.Module, directory: str, suffix: str = "") -> str:
+def save_pretrained(model: nn.Module, directory: str, suffix: str = "", write_config: bool = True) -> str:
     os.makedirs(directory, exist_ok=True)
     m = _unwrap(model)
-    if hasattr(m, "config"):
+    if write_config and hasattr(m, "config"):
         m.config.save(directory)
     from safetensors.torch import save_file
 
@@ -115,12 +115,48 @@ def load_pretrained(directory: str, num_labels: Optional[int] = None, **override
 
 
 # ---------------------------------------------------------------------------------------------------------
+# Training-state checkpoints.  Layout of `directory`:
+#
+#   checkpoint-<step>-<epoch>-<offset>/config.json, model[.<suffix>].safetensors, training_state[.<suffix>].pt
+#   latest[.<suffix>].json            -> names the newest complete subdirectory of this writer
+#
+# A subdirectory is filled first (every file through a temporary name + os.replace) and only then published by
+# replacing latest.json atomically, so a crash at any point leaves the previous checkpoint intact and never pairs
+# new weights with old optimizer moments.  Each subdirectory is itself an HF model directory.  The writers of a
+# model-parallel replica (suffix "stage0" / "stage1") share the subdirectories and publish separately;
+# `common_tag` lets them agree on the newest checkpoint all of them completed.
+def _tag_of(extra: dict) -> str:
+    return f"{int(extra.get('global_step', 0)):08d}-{int(extra.get('epoch', 0))}-{int(extra.get('micro_offset', 0))}"
+
+
+def _names(suffix: str):
+    if not suffix:
+        return WEIGHTS, STATE, "latest.json"
+    return f"model.{suffix}.safetensors", f"training_state.{suffix}.pt", f"latest.{suffix}.json"
+
+
+def _atomic_json(path: str, obj) -> None:
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+
+
 def save_training_state(directory: str, model: nn.Module, optimizer=None, scheduler=None, extra: Optional[dict] = None,
-                        suffix: str = "") -> str:
-    """Weights (HF layout) + everything needed to continue the run bit-for-bit on the same world size."""
-    save_pretrained(model, directory, suffix)
+                        suffix: str = "", write_config: bool = True, keep: int = 2) -> str:
+    """Weights (HF layout) + everything needed to continue the run bit-for-bit on the same world size.  `extra`
+    carries the position of the run (``epoch``, ``global_step``, ``micro_offset`` = batches of the epoch already
+    consumed).  Only one writer of a shared directory should pass ``write_config=True``."""
+    extra = dict(extra or {})
+    wname, sname, lname = _names(suffix)
+    tag = _tag_of(extra)
+    sub = os.path.join(directory, f"checkpoint-{tag}")
+    os.makedirs(sub, exist_ok=True)
+    save_pretrained(model, sub, suffix, write_config=write_config)
     m = _unwrap(model)
-    state = {"extra": extra or {}}
+    state = {"extra": extra}
     opt = getattr(optimizer, "optimizer", optimizer)
     if opt is not None:
         state["optimizer"] = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in opt.state_dict().items()} \
@@ -131,24 +167,82 @@ def save_training_state(directory: str, model: nn.Module, optimizer=None, schedu
     if rt is not None:
         state["rng"] = {"state": rt.rng_state.cpu(), "micro": rt.micro}
     state["torch_rng"] = torch.get_rng_state()
-    name = STATE if not suffix else f"training_state.{suffix}.pt"
-    path = os.path.join(directory, name)
+    path = os.path.join(sub, sname)
     tmp = path + ".tmp"
     torch.save(state, tmp)
     os.replace(tmp, path)
-    with open(os.path.join(directory, "latest.json" if not suffix else f"latest.{suffix}.json"), "w") as f:
-        json.dump({"weights": WEIGHTS if not suffix else f"model.{suffix}.safetensors", "state": name,
-                   "extra": {k: v for k, v in (extra or {}).items() if isinstance(v, (int, float, str, bool))}}, f)
+    _atomic_json(os.path.join(directory, lname), {
+        "dir": f"checkpoint-{tag}", "weights": wname, "state": sname,
+        "extra": {k: v for k, v in extra.items() if isinstance(v, (int, float, str, bool))}})
+    # older checkpoints: this writer removes its own files, the directory goes with its last file
+    mine = sorted(t for t in available_tags(directory, suffix) if t != tag)
+    for old in mine[:max(0, len(mine) - (keep - 1))]:
+        odir = os.path.join(directory, f"checkpoint-{old}")
+        for name in (wname, sname) + (("config.json",) if write_config else ()):
+            try:
+                os.remove(os.path.join(odir, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(odir)
+        except OSError:
+            pass
     return path
 
 
-def load_training_state(directory: str, model: nn.Module, optimizer=None, scheduler=None, suffix: str = "") -> dict:
+def available_tags(directory: str, suffix: str = ""):
+    """Tags of the checkpoints under `directory` for which this writer's two files are complete."""
+    wname, sname, _ = _names(suffix)
+    out = []
+    if not directory or not os.path.isdir(directory):
+        return out
+    for d in os.listdir(directory):
+        if d.startswith("checkpoint-") and all(os.path.exists(os.path.join(directory, d, n)) for n in (wname, sname)):
+            out.append(d[len("checkpoint-"):])
+    return sorted(out)
+
+
+def latest_tag(directory: Optional[str], suffix: str = "") -> Optional[str]:
+    """Tag of the checkpoint this writer published last, or None."""
+    if not directory:
+        return None
+    path = os.path.join(directory, _names(suffix)[2])
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f).get("dir", "")
+    return d[len("checkpoint-"):] if d.startswith("checkpoint-") else None
+
+
+def common_tag(directory: Optional[str], suffix: str, group=None) -> Optional[str]:
+    """Newest checkpoint every rank of `group` can load (collective).  The writers of a model-parallel replica
+    publish one after the other, so after a crash one of them may be a checkpoint ahead of the other."""
+    import torch.distributed as dist
+
+    mine = set(available_tags(directory, suffix)) if directory else set()
+    newest = latest_tag(directory, suffix)
+    mine = {t for t in mine if newest is not None and t <= newest}  # nothing newer than what was published
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return max(mine) if mine else None
+    every = [None] * dist.get_world_size(group)
+    dist.all_gather_object(every, sorted(mine), group=group)
+    common = set(every[0]).intersection(*map(set, every[1:]))
+    return max(common) if common else None
+
+
+def load_training_state(directory: str, model: nn.Module, optimizer=None, scheduler=None, suffix: str = "",
+                        tag: Optional[str] = None) -> dict:
+    """Restore what :func:`save_training_state` wrote (the newest published checkpoint, or `tag`); returns `extra`.
+    Nothing from the files is executed: safetensors for the weights, ``weights_only=True`` for the state."""
     from safetensors.torch import load_file
 
-    wname = WEIGHTS if not suffix else f"model.{suffix}.safetensors"
-    load_state_dict_into(model, load_file(os.path.join(directory, wname)), strict=True)
-    name = STATE if not suffix else f"training_state.{suffix}.pt"
-    state = torch.load(os.path.join(directory, name), map_location="cpu", weights_only=False)
+    wname, sname, _ = _names(suffix)
+    tag = tag or latest_tag(directory, suffix)
+    if tag is None:
+        raise FileNotFoundError(f"no published checkpoint in {directory}")
+    sub = os.path.join(directory, f"checkpoint-{tag}")
+    load_state_dict_into(model, load_file(os.path.join(sub, wname)), strict=True)
+    state = torch.load(os.path.join(sub, sname), map_location="cpu", weights_only=True)
     opt = getattr(optimizer, "optimizer", optimizer)
     if opt is not None and "optimizer" in state:
         opt.load_state_dict(state["optimizer"])
@@ -165,6 +259,4 @@ def load_training_state(directory: str, model: nn.Module, optimizer=None, schedu
 
 
 def has_checkpoint(directory: Optional[str], suffix: str = "") -> bool:
-    if not directory:
-        return False
-    return os.path.exists(os.path.join(directory, "latest.json" if not suffix else f"latest.{suffix}.json"))
+    return latest_tag(directory, suffix) is not None

@@ -92,6 +92,11 @@ class DeviceLoader:
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
 
+    def skip_batches(self, n: int) -> None:
+        """Leave the first `n` batches of this rank out of the next iteration (resume inside an epoch).  With a
+        :class:`ShardedBatchSampler` they are skipped as index lists, before any collation or copy."""
+        self._skip = max(0, int(n))
+
     def _to_device(self, batch):
         if self._stream is None:
             return batch.to(self.device) if hasattr(batch, "to") else batch
@@ -107,7 +112,12 @@ class DeviceLoader:
         for s in _samplers_of(self.loader):
             s.set_epoch(self.epoch)
         self.epoch += 1
+        skip, self._skip = getattr(self, "_skip", 0), 0
+        if skip and isinstance(self.loader.batch_sampler, ShardedBatchSampler):
+            self.loader.batch_sampler.skip_next, skip = skip, 0
         it = iter(self.loader)
+        for _ in range(skip):  # (a loader that is not batch-sharded: the skipped batches are built and dropped)
+            next(it, None)
         if self._stream is None:
             for b in it:
                 yield self._to_device(b)

@@ -25,6 +25,13 @@ class ShardedBatchSampler(Sampler):
         self.num_processes, self.process_index, self.even_batches = num_processes, process_index, even_batches
         self.batch_size = getattr(batch_sampler, "batch_size", None)
         self.drop_last = getattr(batch_sampler, "drop_last", False)
+        self.skip_next = 0  # batches of this rank to leave out of the NEXT iteration (mid-epoch resume)
+
+    def __iter__(self) -> Iterator[List[int]]:
+        skip, self.skip_next = self.skip_next, 0
+        for i, b in enumerate(self._batches()):
+            if i >= skip:
+                yield b
 
     def __len__(self) -> int:
         n, w = len(self.batch_sampler), self.num_processes
@@ -36,7 +43,7 @@ class ShardedBatchSampler(Sampler):
             return n // w + 1
         return n // w + (1 if self.process_index < n % w else 0)
 
-    def __iter__(self) -> Iterator[List[int]]:
+    def _batches(self) -> Iterator[List[int]]:
         w, r = self.num_processes, self.process_index
         batches = [list(b) for b in self.batch_sampler]
         if not batches:

@@ -63,8 +63,10 @@ class EncoderConfig:
 
     def save(self, directory: str) -> None:
         os.makedirs(directory, exist_ok=True)
-        with open(os.path.join(directory, "config.json"), "w") as f:
+        path = os.path.join(directory, "config.json")
+        with open(path + ".tmp", "w") as f:
             json.dump(self.to_hf_dict(), f, indent=2, sort_keys=True)
+        os.replace(path + ".tmp", path)
 
     @classmethod
     def from_hf_dict(cls, d: Dict) -> "EncoderConfig":

@@ -172,9 +172,12 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
     """One forward(+backward) of a tower-parallel replica.  Returns (loss, logits) on the first rank."""
     inner = module.module if hasattr(module, "module") and isinstance(module.module, _TowerRank) else module
     dp = module if inner is not module else None
-    if dp is not None:
-        dp.auto_arm = False
     rt = inner.runtime
+    if dp is not None:
+        # the armed window of the first rank spans two backward() calls (tower 1 + head, then the embedding lookup),
+        # so it is closed explicitly after the second one instead of by autograd's end-of-backward callback
+        dp.auto_arm = False
+        dp.manual_finish = True
     if rt is not None and train:
         rt.next_micro()
     dev = engine.device
@@ -203,13 +206,20 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
                 return out.loss, out.logits
             scale = engine.scaler.scale_tensor() if engine.scaler.enabled else None
             loss = out.loss * scale.to(out.loss.dtype) if scale is not None else out.loss
+            emb_seg = arena.seg_index.get("bert_1.embeddings") if arena is not None else None
+            if rt is not None and emb_seg is not None:
+                rt.hold.add(emb_seg)  # its word-embedding gradient only arrives with the second backward below
+            if dp is not None:
+                dp.prepare_backward()  # layer buckets are reduced while the rest of this backward still runs
             # tower-1 / head gradients; d(s23) goes to the second rank, which answers with d(embedding)
             loss.backward()
             d_emb = torch.empty(B, S, H, dtype=adt, device=dev)
             _p2p([dist.P2POp(dist.isend, s23.grad.contiguous(), peer1), dist.P2POp(dist.irecv, d_emb, peer1)])
-            if dp is not None:
-                dp.prepare_backward()  # the final backward closes the window: every bucket is reduced after it
             emb.backward(emb_in.grad.to(emb.dtype) + d_emb.to(emb.dtype))
+            if rt is not None:
+                rt.release()
+            if dp is not None:
+                dp.finish_backward()  # the embedding bucket (and anything unused) is reduced here; then the join
             return out.loss.detach(), out.logits
         emb = torch.empty(B, S, H, dtype=adt, device=dev)
         _p2p([dist.P2POp(dist.irecv, emb, peer0)])
@@ -226,6 +236,8 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
         if dp is not None:
             dp.prepare_backward()
         s.backward(ds)
+        if dp is not None:
+            dp.finish_backward()
         _p2p([dist.P2POp(dist.isend, emb.grad.contiguous(), peer0)])
         return None, None
 
@@ -287,7 +299,10 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
                 pending = 0
                 global_step += 1
                 if loss is not None:
-                    if log_rank:
+                    record = global_step % cfg.log_every == 0 or bool(cfg.max_steps)
+                    if record and mesh.dp > 1:
+                        loss = engine.reduce_mean(loss)  # global-batch loss: mean over the replicas' shards
+                    if log_rank and record:
                         losses.append(float(loss.item()))
                     logger.log_step(global_step, loss, sched.get_last_lr()[0], engine.scaler)
                 if cfg.max_steps and global_step >= cfg.max_steps:
@@ -307,10 +322,14 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
         dist.barrier()
         if done:
             break
+    replicas_equal = None
+    if inner_dp is not None:
+        inner_dp.check_replicas()  # raises if a gradient ever missed its reduction
+        replicas_equal = True
     box = [result if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     out = dict(box[0] or {})
-    out.update({"optimizer_steps": global_step, "wall_s": time.perf_counter() - t0, "losses": losses,
+    out.update({"optimizer_steps": global_step, "replicas_bit_equal": replicas_equal, "wall_s": time.perf_counter() - t0, "losses": losses,
                 "stage": mesh.stage, "replica": mesh.replica})
     logger.close()
     return out

@@ -28,6 +28,10 @@ class NativeRuntime:
         self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=arena.device)
         self.micro = 0  # global micro-batch counter; part of every dropout counter
         self.segment_done: Optional[Callable[[int], None]] = None  # set by the DP reducer wrapper
+        # segments whose completion is reported later, by release(): a segment that gets part of its gradient outside
+        # its native node (the word-embedding table of a tower-parallel rank, filled by a second backward call)
+        self.hold: set = set()
+        self._held: List[int] = []
 
     def reseed(self, seed: int) -> None:
         self.rng_state[0] = seed
@@ -37,8 +41,17 @@ class NativeRuntime:
         return self.micro
 
     def done(self, seg: int) -> None:
-        if self.segment_done is not None:
+        if seg in self.hold:
+            self._held.append(seg)
+        elif self.segment_done is not None:
             self.segment_done(seg)
+
+    def release(self) -> None:
+        """Report the held segments that completed since the last call."""
+        held, self._held = self._held, []
+        if self.segment_done is not None:
+            for seg in held:
+                self.segment_done(seg)
 
 
 class LayerNative:

@@ -14,12 +14,16 @@ which drives the same RCCL library.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
 
-_COMMS: Dict[int, object] = {}
+# communicators of this process, keyed by the global ranks they span (a group object's id() can be reused after the
+# group is garbage collected; its rank tuple cannot mean anything else)
+_COMMS: Dict[tuple, object] = {}
+_LOCK = threading.Lock()  # held by the watchdog's poll and by close_all()
 
 
 def backend_choice(explicit: Optional[str] = None) -> str:
@@ -35,7 +39,10 @@ def create_rccl_comm(group=None, device: Optional[torch.device] = None):
     no process group gets a 1-rank communicator).  Collective over the group: every member must call it."""
     from ..ops import native
 
-    key = id(group) if group is not None else 0
+    if dist.is_initialized():
+        key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    else:
+        key = (0,)
     if key in _COMMS:
         return _COMMS[key]
     C = native()
@@ -64,6 +71,7 @@ def create_rccl_comm(group=None, device: Optional[torch.device] = None):
 
 def close_all() -> None:
     """Orderly teardown of every communicator this process opened (collective: call it on every rank)."""
-    for comm in _COMMS.values():
-        comm.close()
-    _COMMS.clear()
+    with _LOCK:
+        for comm in _COMMS.values():
+            comm.close()
+        _COMMS.clear()

@@ -125,6 +125,9 @@ class DataParallel(nn.Module):
         self.world_size = dist.get_world_size(self.pg)
         self.require_sync = True
         self.auto_arm = True  # forward() arms the reducer; a pipeline driver arms it itself before the last backward
+        # True: the window is closed by an explicit finish_backward() instead of autograd's end-of-backward callback
+        # (a driver whose armed window spans several backward() calls, e.g. the tower-parallel layout)
+        self.manual_finish = False
         self._armed = False
         self._callback_queued = False
         self.measure_exposed = os.environ.get("PDT_COMM_TIMING", "0") not in ("", "0")
@@ -170,6 +173,25 @@ class DataParallel(nn.Module):
                                f"(arena elements / parameters / buckets / layout hash: "
                                f"{[t.tolist() for t in every]})")
 
+    def check_replicas(self) -> None:
+        """Raise unless every rank of the group holds bit-identical master parameters (host sync; collective).
+        Data-parallel replicas start from one broadcast and apply the same all-reduced gradients with the same
+        deterministic optimizer kernel, so any difference means a gradient that missed its reduction."""
+        if self.world_size == 1:
+            return
+        m = self.arena.master
+        bits = torch.sum(m.view(torch.int32), dtype=torch.int64)  # wrap-around sum of the raw words
+        mine = torch.stack([bits, torch.sum(m, dtype=torch.float64).view(torch.int64)])
+        if dist.get_backend(self.pg) != "nccl":
+            mine = mine.cpu()
+        every = [torch.empty_like(mine) for _ in range(self.world_size)]
+        dist.all_gather(every, mine, group=self.pg)
+        bad = [r for r, t in enumerate(every) if not torch.equal(t, every[0])]
+        if bad:
+            sums = [float(t[1:].view(torch.float64)) for t in every]
+            raise RuntimeError(f"data-parallel replicas diverged: parameters of group ranks {bad} differ from rank 0 "
+                               f"(parameter sums per rank: {sums})")
+
     # -- reducer plumbing ----------------------------------------------------------------------------
     def _make_hook(self, bucket: int):
         def hook(_p):
@@ -179,7 +201,7 @@ class DataParallel(nn.Module):
     def _mark(self, bucket: int) -> None:
         if not self._armed:
             return
-        if not self._callback_queued:
+        if not self._callback_queued and not self.manual_finish:
             # end-of-backward callback, queued from inside the running backward pass
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
             self._callback_queued = True

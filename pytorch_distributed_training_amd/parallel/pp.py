@@ -293,11 +293,15 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
         dist.barrier()
         if done:
             break
+    replicas_equal = None
+    if pipe.dp is not None:
+        pipe.dp.check_replicas()  # raises if a gradient ever missed its reduction
+        replicas_equal = True
     # every rank returns the metric of the last stage of replica 0
     box = [result if (mesh.is_last_stage and mesh.replica == 0) else None]
     dist.broadcast_object_list(box, src=ParallelMesh(world_size, 0, 2).peer(1))
     out = dict(box[0] or {})
-    out.update({"optimizer_steps": global_step, "wall_s": time.perf_counter() - t0, "losses": losses,
+    out.update({"optimizer_steps": global_step, "replicas_bit_equal": replicas_equal, "wall_s": time.perf_counter() - t0, "losses": losses,
                 "stage": mesh.stage, "replica": mesh.replica})
     logger.close()
     return out

@@ -119,16 +119,21 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     horizon = micro_per_epoch * cfg.num_epochs if cfg.compat else steps_per_epoch * cfg.num_epochs
     lr_scheduler = get_linear_schedule_with_warmup(optimizer, cfg.num_warmup_steps, horizon)
 
-    start_epoch, global_step = 0, 0
+    # resume (an explicit --resume, or the newest checkpoint of --output-dir after an elastic restart): weights,
+    # optimizer, schedule, RNG counters, and the position inside the epoch - the batches already consumed are
+    # skipped as index lists, so the run continues with exactly the batch an uninterrupted run would see next
+    start_epoch, global_step, start_micro = 0, 0, 0
     resume_dir = cfg.resume or (cfg.output_dir if ckpt.has_checkpoint(cfg.output_dir) else None)
     if resume_dir and ckpt.has_checkpoint(resume_dir):
         extra = ckpt.load_training_state(resume_dir, model, optimizer, lr_scheduler)
         start_epoch, global_step = int(extra.get("epoch", 0)), int(extra.get("global_step", 0))
-        engine.print(f"resumed from {resume_dir}: epoch {start_epoch}, optimizer step {global_step}")
+        start_micro = int(extra.get("micro_offset", 0))
+        engine.print(f"resumed from {resume_dir}: epoch {start_epoch}, batch {start_micro}, optimizer step {global_step}")
 
     logger = StepLogger(engine.is_main_process, cfg.log_every, cfg.log_file,
                         samples_per_step=micro_bs * accum * engine.num_processes)
     dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), engine.process_index)
+    tail = micro_per_epoch % accum  # micro-batches of the partial window that ends an epoch (0: none)
     # PDT_COMM_TIMING=1: the log line carries the gradient-communication time that backward did not hide
     comm_extra = (lambda: {"comm_exposed_ms": model.comm_exposed_ms()}) if getattr(model, "measure_exposed", False) else None
     last_metric: dict = {}
@@ -139,7 +144,11 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
         if hasattr(train_dl, "set_epoch"):
             train_dl.set_epoch(epoch)
         pending = 0
-        for step, batch in enumerate(train_dl):
+        first = start_micro if epoch == start_epoch else 0
+        if first and hasattr(train_dl, "skip_batches"):
+            train_dl.skip_batches(first)
+        for step, batch in enumerate(train_dl, start=first):
+            window = accum
             if cfg.compat:
                 fire = step % accum == 0
                 sync_ctx = _Null()  # the reference's DP script reduces on every micro-batch
@@ -147,11 +156,13 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                 pending += 1
                 fire = pending == accum or step == micro_per_epoch - 1
                 sync_ctx = _Null() if fire else engine.no_sync(model)
+                if tail and step >= micro_per_epoch - tail:
+                    window = tail  # the flushed partial window is a mean over its own micro-batches
             logger.add_tokens(batch["input_ids"].numel() * engine.num_processes)
             with sync_ctx:
                 with trace_range("forward"):
                     outputs = model(**batch)
-                    loss = outputs.loss / accum
+                    loss = outputs.loss / window
                 with trace_range("backward+reduce" if fire else "backward"):
                     engine.backward(loss)
             if fire:
@@ -163,10 +174,10 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                 global_step += 1
                 dog.heartbeat()
                 inject_fault(engine.process_index, global_step)
-                logger.log_step(global_step, loss * accum, lr_scheduler.get_last_lr()[0], engine.scaler, comm_extra)
+                logger.log_step(global_step, loss * window, lr_scheduler.get_last_lr()[0], engine.scaler, comm_extra)
                 if cfg.save_every and cfg.output_dir and global_step % cfg.save_every == 0 and engine.is_main_process:
                     ckpt.save_training_state(cfg.output_dir, model, optimizer, lr_scheduler,
-                                             {"epoch": epoch, "global_step": global_step})
+                                             {"epoch": epoch, "global_step": global_step, "micro_offset": step + 1})
                 if cfg.max_steps and global_step >= cfg.max_steps:
                     done = True
                     break
@@ -180,6 +191,9 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
             break
     dog.close()
     logger.close()
+    if hasattr(model, "check_replicas"):
+        model.check_replicas()  # raises if a gradient ever missed its reduction
+        last_metric["replicas_bit_equal"] = True
     last_metric["optimizer_steps"] = global_step
     last_metric["wall_s"] = time.perf_counter() - t_start
     return last_metric

@@ -44,20 +44,29 @@ class StepWatchdog:
                 os._exit(75)
 
     def close(self) -> None:
+        """Stop the thread and wait for it: after this returns nothing polls the communicators any more, so they
+        can be closed."""
         self._stop.set()
+        if self._thread is not None and self._thread is not threading.current_thread():
+            self._thread.join(timeout=10.0)
+            self._thread = None
 
 
 def poll_comm_errors() -> Optional[str]:
     """First asynchronous RCCL error recorded on any communicator this process opened, or None."""
     try:
-        from ..parallel.comm import _COMMS
+        from ..parallel.comm import _COMMS, _LOCK
     except Exception:  # pragma: no cover - partial installs
         return None
-    for comm in list(_COMMS.values()):
-        try:
-            comm.check_async_error()
-        except RuntimeError as e:
-            return str(e).splitlines()[0]
+    with _LOCK:  # close_all() takes the same lock: a communicator is never destroyed under this poll
+        for comm in list(_COMMS.values()):
+            try:
+                comm.check_async_error()
+            except RuntimeError as e:
+                msg = str(e).splitlines()[0]
+                if "communicator is closed" in msg:
+                    continue  # closed in an orderly way, not an RCCL error
+                return msg
     return None
 
 

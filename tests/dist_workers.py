@@ -192,17 +192,17 @@ def single_process_reference(batch_size, steps=6):
     return losses
 
 
-def tower_recipe(rank, world):
+def tower_recipe(rank, world, examples=32):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
-    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=32, eval_examples=8, num_epochs=1,
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=examples, eval_examples=8, num_epochs=1,
                       batch_size=8, max_gpu_batch_size=8, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=4,
-                      seed=5, mp_layout="towers")
+                      seed=5, mp_layout="towers", min_bucket_mb=0.05)
     return run_model_parallel(rank, world, cfg)
 
 
-def tribert_single_process(steps=4):
+def tribert_single_process(steps=4, batch_size=8, examples=32):
     """TriBert in one process on the same data / seeds as tower_recipe: the loss curve to match."""
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
@@ -211,12 +211,12 @@ def tribert_single_process(steps=4):
     from pytorch_distributed_training_amd.recipes import _collator, build_datasets
     from pytorch_distributed_training_amd.utils.seed import set_seed
 
-    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=32, eval_examples=8, num_epochs=1,
-                      batch_size=8, seed=5)
+    cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=examples, eval_examples=8, num_epochs=1,
+                      batch_size=batch_size, seed=5)
     eng = Engine(cpu=True, seed=5)
     mc = preset(cfg.model)
     train_ds, _ = build_datasets(cfg, mc)
-    dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=8)
+    dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=batch_size)
     set_seed(5)
     torch.manual_seed(5)
     model = TriBert(build_model(mc), build_model(mc), build_model(mc))
@@ -270,10 +270,14 @@ def gpu_dp_native(rank, world):
             "nb": model.reducer.num_buckets()}
 
 
-def gpu_pipeline_recipe(rank, world, layout):
+def gpu_pipeline_recipe(rank, world, layout, debug=False):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
+    if debug:  # arena guard words + "optimizer step while a reduction is still armed" check
+        import os
+
+        os.environ["PDT_DEBUG"] = "1"
     cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
                       seed=5, mp_layout=layout, init_scale=256.0)
@@ -282,7 +286,7 @@ def gpu_pipeline_recipe(rank, world, layout):
     return run_model_parallel(rank, world, cfg)
 
 
-def gpu_single_reference(layout, steps=6):
+def gpu_single_reference(layout, steps=6, replicas=1):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
     from pytorch_distributed_training_amd.models.tribert import TriBert
@@ -290,7 +294,7 @@ def gpu_single_reference(layout, steps=6):
     from pytorch_distributed_training_amd.recipes import _collator, build_datasets
     from pytorch_distributed_training_amd.utils.seed import set_seed
 
-    bs = 8 if layout == "towers" else 16
+    bs = (8 if layout == "towers" else 16) * replicas  # the global batch of `replicas` data-parallel replicas
     cfg = TrainConfig(model="bert-tiny-nodrop", fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=bs, seed=5)
     eng = Engine(fp16=True, seed=5, init_scale=256.0)

@@ -20,23 +20,33 @@ def test_dp_native_gradients_match_big_batch_two_ranks_one_gpu():
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_pipeline_native_loss_curve(world):
-    ref = W.gpu_single_reference("pipeline")
+    """1 or 2 replicas of the 2-stage pipeline against ONE process on the same global batch (16 resp. 32 samples)."""
+    replicas = world // 2
+    steps = 6 if replicas == 1 else 4  # 64 examples, 2 epochs: 4 resp. 2 optimizer steps per epoch
+    ref = W.gpu_single_reference("pipeline", steps=steps, replicas=replicas)
     res = run_distributed(W.gpu_pipeline_recipe, world, args=("pipeline",))
     got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
-    if world == 4:  # 2 replicas x per-replica batch 16 = global batch 32 => 2 steps per epoch, other batches
-        assert len(got) == 4 and all(x == x and x < 1.5 for x in got)
-        return
-    assert len(got) == len(ref) == 6
+    assert len(got) == len(ref) == steps, (got, ref)
     for a, b in zip(got, ref):
         assert abs(a - b) < 2e-2, (got, ref)
+    assert all(r["replicas_bit_equal"] in (True, None) for r in res)
 
 
-def test_tower_parallel_native_loss_curve():
-    ref = W.gpu_single_reference("towers", steps=4)
-    res = run_distributed(W.gpu_pipeline_recipe, 2, args=("towers",))
-    got = [r for r in res if r["stage"] == 0][0]["losses"][:4]
+@pytest.mark.parametrize("world", [2, 4])
+def test_tower_parallel_native_loss_curve(world):
+    """TriBert towers over rank pairs; with 4 ranks two such pairs are data parallel (fp16, debug guards on): the
+    logged loss is the one of a single-process TriBert on the global batch and the replicas stay bit-identical -
+    the embedding bucket of the first tower rank completes in a second backward call and must still be reduced in
+    the step it belongs to (/root/reference/test_model_parallelism.py:248-253,292-299)."""
+    replicas = world // 2
+    ref = W.gpu_single_reference("towers", steps=4, replicas=replicas)
+    res = run_distributed(W.gpu_pipeline_recipe, world, args=("towers", world == 4))
+    got = [r for r in res if r["stage"] == 0 and r["replica"] == 0][0]["losses"][:4]
+    assert len(got) == 4
     for a, b in zip(got, ref):
         assert abs(a - b) < 2e-2, (got, ref)
+    if world == 4:
+        assert all(r["replicas_bit_equal"] is True for r in res)
 
 
 def test_rccl_call_path_single_rank():
@@ -109,19 +119,26 @@ torch.cuda.synchronize()
 assert torch.equal(z, x * 3.0 + 1.0)
 for dt in (torch.float16, torch.bfloat16, torch.float32, torch.int64, torch.int32):
     t = torch.arange(1000).to(dt).cuda(); ref = t.clone()
-    # (drained after every call: a burst of 1-rank collectives on 4-byte types was measured to stall for ~90 s inside
-    # RCCL on this stack, which says nothing about the communicator and would only slow the test down)
-    comm.all_reduce(t); torch.cuda.synchronize()
-    comm.broadcast(t, 0); torch.cuda.synchronize()
-    out = torch.empty_like(t); comm.all_gather(out, t); torch.cuda.synchronize()
-    rs = torch.empty_like(t); comm.reduce_scatter(rs, out); torch.cuda.synchronize()
+    comm.all_reduce(t); comm.broadcast(t, 0)           # (no host synchronisation between the calls)
+    out = torch.empty_like(t); comm.all_gather(out, t)
+    rs = torch.empty_like(t); comm.reduce_scatter(rs, out)
     assert torch.equal(out, ref) and torch.equal(rs, ref), dt
+# 40 fork -> collective -> join rounds back to back on the null stream, nothing else in the queues: with a
+# communication stream of elevated priority this chain never drained (bench/dev/rccl_stall.cpp)
+import time
+t = torch.arange(1000, dtype=torch.float32).cuda(); ref = t.clone(); torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(40):
+    comm.all_reduce(t)
+torch.cuda.synchronize()
+assert time.time() - t0 < 5.0, f"chain of 40 collectives took {time.time() - t0:.1f} s"
+assert torch.equal(t, ref) and comm.comm_count() == 1
 src = torch.randn(4096, 64, device="cuda", dtype=torch.float16); dst = torch.zeros_like(src)
 comm.p2p([0, 1], [src, dst], [0, 0])          # batched send + recv (to itself: one group call)
 torch.cuda.synchronize()
 assert torch.equal(src, dst)
 comm.barrier(); comm.check_async_error()
-assert comm.collectives() >= 22 and comm.bytes() > 0
+assert comm.collectives() >= 62 and comm.bytes() > 0
 close_all()
 print("NATIVE_RCCL_OK")
 '''

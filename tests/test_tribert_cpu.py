@@ -69,3 +69,18 @@ def test_tower_parallel_matches_single_process_tribert():
     assert len(got) == len(ref) == 4
     for a, b in zip(got, ref):
         assert abs(a - b) < 2e-5, (got, ref)
+
+
+def test_tower_parallel_times_data_parallel_matches_single_process_tribert():
+    """2 replicas x 2 tower ranks (the reference wraps its two-device TriBert in DDP with unused parameters,
+    /root/reference/test_model_parallelism.py:248-253): the logged loss is the loss of the global batch, every
+    bucket - the embedding bucket that completes in a second backward call included - is reduced in the window
+    it belongs to (the recipe verifies bit-equal replicas at its end)."""
+    ref = W.tribert_single_process(batch_size=16, examples=64)
+    res = run_distributed(W.tower_recipe, 4, args=(64,))
+    assert all(r["optimizer_steps"] == 4 for r in res)
+    got = [r for r in res if r["stage"] == 0 and r["replica"] == 0][0]["losses"]
+    assert len(got) == len(ref) == 4
+    for a, b in zip(got, ref):
+        assert abs(a - b) < 2e-5, (got, ref)
+    assert all(r["replicas_bit_equal"] for r in res)
