@@ -60,8 +60,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp16", "bf16"])
     ap.add_argument("--comm", default=None, choices=[None, "c10d", "rccl"],
-                    help="gradient all-reduce through torch's RCCL process group (c10d, default) or through the framework's "
-                         "own RCCL communicator and communication stream (rccl)")
+                    help="gradient all-reduce and pipeline send/recv through the framework's own RCCL communicator and "
+                         "communication stream (rccl, default) or through torch's RCCL process group (c10d)")
     ap.add_argument("--pp", type=int, default=1, choices=[1, 2],
                     help="2 = every data-parallel replica is a 2-stage layer-split pipeline over a pair of GPUs (1F1B over "
                          "send/recv); N GPUs = N/2 replicas.  The per-replica batch is 2 x --batch, so the work per GPU is "
@@ -180,7 +180,7 @@ def main() -> None:
             "final_loss": float(loss.item()) * args.accum,
             "tokens_per_s": round(value * args.seq_len, 1),
             "comm_exposed_ms_per_step": exposed,
-            "rccl_ranks": _rccl_ranks(eng.pg),
+            "rccl_ranks": model.rccl_ranks() if hasattr(model, "rccl_ranks") else 0,
             "replicas_bit_equal": replicas_equal,
             # not a published number (the reference has none, hence vs_baseline = null): the reference's software
             # stack (transformers + torch AMP, SDPA attention) measured on one MI355X at this configuration with
@@ -191,7 +191,7 @@ def main() -> None:
             "config": {"model": args.model, "global_batch": global_batch, "per_gpu_batch": args.batch,
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
-                       "comm_backend": args.comm or os.environ.get("PDT_COMM", "c10d"),
+                       "comm_backend": getattr(model, "backend_label", "none"),
                        "gemm_persistent_mode": _persist_mode(),
                        "hip_graph": bool(args.graph),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,
@@ -215,13 +215,6 @@ def _self_launch(gpus: int) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(find_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     return subprocess.run(cmd).returncode
-
-
-def _rccl_ranks(group=None) -> int:
-    """Ranks of the gradient group that talk RCCL ("nccl" backend on ROCm); 0 for single-process and gloo runs."""
-    if not dist.is_initialized() or dist.get_backend(group) != "nccl":
-        return 0
-    return dist.get_world_size(group)
 
 
 def _check_replicas(model):
@@ -311,11 +304,13 @@ def bench_pipeline(args, world: int, comm) -> None:
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
             "final_loss": box[0], "tokens_per_s": round(value * args.seq_len, 1),
             "comm_exposed_ms_per_step": round(exposed, 3) if exposed is not None else None,
-            "rccl_ranks": _rccl_ranks(None), "replicas_bit_equal": replicas_equal,
+            "rccl_ranks": stage.rccl_ranks() if hasattr(stage, "rccl_ranks") else 0,
+            "pipeline_p2p": "rccl" if pipe.comm is not None else "c10d:" + dist.get_backend(),
+            "replicas_bit_equal": replicas_equal,
             "config": {"model": args.model, "global_batch": global_batch, "per_replica_batch": replica_batch,
                        "micro_batches": args.micro_batches, "seq_len": args.seq_len,
                        "parallelism": f"dp{mesh.dp} x pp2 (1F1B)", "backend": dist.get_backend(),
-                       "comm_backend": args.comm or os.environ.get("PDT_COMM", "c10d"),
+                       "comm_backend": getattr(stage, "backend_label", "none"),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        "optimizer": "fused AdamW + dynamic loss scale", "dropout": 0.1},
         }))

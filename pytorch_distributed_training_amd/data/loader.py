@@ -115,7 +115,12 @@ class DeviceLoader:
         skip, self._skip = getattr(self, "_skip", 0), 0
         if skip and isinstance(self.loader.batch_sampler, ShardedBatchSampler):
             self.loader.batch_sampler.skip_next, skip = skip, 0
+        # (a DataLoader iterator draws a base seed from the global torch generator when it is created; put the
+        # generator back so that iterating the data never shifts the dropout stream of a CPU run - a run resumed in
+        # the middle of an epoch creates one iterator more than the uninterrupted run it has to reproduce)
+        rng = torch.get_rng_state()
         it = iter(self.loader)
+        torch.set_rng_state(rng)
         for _ in range(skip):  # (a loader that is not batch-sharded: the skipped batches are built and dropped)
             next(it, None)
         if self._stream is None:

@@ -74,6 +74,14 @@ def init_distributed(cpu: bool = False, backend: Optional[str] = None, timeout_s
         kw = {}
         if backend == "nccl":
             kw["device_id"] = device  # eager communicator creation, binds the rank to its GPU
+        restart = int(os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") or 0)
+        if restart > 0 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+            # A worker group restarted by torch.distributed.run (--max-restarts) on a fixed --master-port talks to the
+            # SAME agent-hosted store as the group that died: the addresses its ranks published are still there, and
+            # a new rank would try to connect to a dead peer.  Every attempt gets a key space of its own.
+            store = dist.TCPStore(env.master_addr, env.master_port, env.world_size, is_master=False,
+                                  timeout=datetime.timedelta(seconds=timeout_s))
+            kw["store"] = dist.PrefixStore(f"/pdt/attempt_{restart}", store)
         dist.init_process_group(backend, rank=env.rank, world_size=env.world_size,
                                 timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return env, device
@@ -83,8 +91,15 @@ def shutdown() -> None:
     """Destroy the default process group.  Objects that hold the group from C++ (bucket reducers) are collected
     first: a group that outlives this call is torn down at interpreter exit, with its worker threads still running."""
     import gc
+    import sys
 
     gc.collect()
+    if sys.exc_info()[0] is None:
+        # orderly end of a run: close the framework's own RCCL communicators (a collective teardown - skipped when the
+        # run is ending with an exception, where a peer may already be gone)
+        from .parallel.comm import close_all
+
+        close_all()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -246,6 +246,7 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     """TriBert training with the towers spread over rank pairs, data parallel across pairs."""
     from torch.utils.data import DataLoader
 
+    from .. import checkpoint as ckpt
     from .. import launch
     from ..engine import Engine
     from ..metrics import load_metric
@@ -254,7 +255,8 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     from ..parallel.groups import ParallelMesh
     from ..recipes import _collator, build_datasets
     from ..utils.logging import StepLogger
-    from ..utils.seed import set_seed
+    from ..utils.seed import seed_step, set_seed
+    from ..utils.watchdog import StepWatchdog, inject_fault
 
     launch.init_distributed(cpu=cfg.cpu)
     mesh = ParallelMesh(world_size, rank, pp=2).build_groups()
@@ -281,12 +283,34 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     losses, result, global_step, done = [], {}, 0, False
     t0 = time.perf_counter()
     inner_dp = part if hasattr(part, "no_sync") else None
-    for epoch in range(cfg.num_epochs):
+    # checkpoints: every tower rank saves its own towers; resume from the newest checkpoint both ranks completed
+    suffix = f"tower{mesh.stage}"
+    start_epoch, start_micro = 0, 0
+    resume_dir = cfg.resume or cfg.output_dir
+    tag = ckpt.common_tag(resume_dir, suffix) if resume_dir else None
+    if tag is not None:
+        extra = ckpt.load_training_state(resume_dir, part, optimizer, sched, suffix, tag=tag)
+        start_epoch, global_step = int(extra.get("epoch", 0)), int(extra.get("global_step", 0))
+        start_micro = int(extra.get("micro_offset", 0))
+        engine.print(f"resumed from {resume_dir}/checkpoint-{tag}: epoch {start_epoch}, batch {start_micro}")
+    dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), rank)
+    seed_step(cfg.seed, rank, global_step)
+
+    def save(epoch: int, offset: int) -> None:
+        if cfg.output_dir and engine.is_main_process:
+            ckpt.save_training_state(cfg.output_dir, part, optimizer, sched,
+                                     {"epoch": epoch, "global_step": global_step, "micro_offset": offset}, suffix,
+                                     write_config=mesh.stage == 0)
+
+    for epoch in range(start_epoch, cfg.num_epochs):
         part.train()
         train_dl.set_epoch(epoch)
         pending = 0
         n_micro = len(train_dl)
-        for step, batch in enumerate(train_dl):
+        first = start_micro if epoch == start_epoch else 0
+        if first:
+            train_dl.skip_batches(first)
+        for step, batch in enumerate(train_dl, start=first):
             pending += 1
             fire = pending == accum or step == n_micro - 1
             if inner_dp is not None:
@@ -298,6 +322,11 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
                 optimizer.zero_grad()
                 pending = 0
                 global_step += 1
+                seed_step(cfg.seed, rank, global_step)
+                dog.heartbeat()
+                if cfg.save_every and global_step % cfg.save_every == 0:
+                    save(epoch, step + 1)
+                inject_fault(rank, global_step)
                 if loss is not None:
                     record = global_step % cfg.log_every == 0 or bool(cfg.max_steps)
                     if record and mesh.dp > 1:
@@ -319,9 +348,11 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
                 metric.add_batch(predictions=preds, references=refs, valid=valid)
         result = metric.compute() if mesh.stage == 0 else {}
         logger.log_epoch(epoch, result)
+        save(epoch + 1, 0)
         dist.barrier()
         if done:
             break
+    dog.close()
     replicas_equal = None
     if inner_dp is not None:
         inner_dp.check_replicas()  # raises if a gradient ever missed its reduction

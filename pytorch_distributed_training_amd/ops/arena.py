@@ -257,6 +257,16 @@ class ParamArena:
             if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):
                 self.grad[seg.start:seg.end].zero_()
 
+    def zero_unwritten(self) -> None:
+        """Before the optimizer reads the gradients: a slice that zero_grad() left alone because its native producer
+        overwrites it, but whose producer did NOT run in this window (a layer outside the graph of this step), still
+        holds the previous window's values - clear it, so that "no gradient" means zero for every kind of segment."""
+        if self.p16 is None or not self.master.is_cuda:
+            return
+        for i, seg in enumerate(self.segments):
+            if seg.native_overwrite and not self.written[i]:
+                self.grad[seg.start:seg.end].zero_()
+
     def take_accumulate_flag(self, seg_idx: int) -> bool:
         """True if the native producer must add to the slice, False if it may overwrite it."""
         acc = self.written[seg_idx]

@@ -87,6 +87,7 @@ class FusedAdamW:
         """`overflow_group`: ranks that must agree on skipping the step (the stages of one pipeline replica:
         an inf on one stage's gradients has to skip the update on all of them)."""
         a = self.arena
+        a.zero_unwritten()
         if a.master.is_cuda:
             from .ops import native
 

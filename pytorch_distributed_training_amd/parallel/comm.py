@@ -8,8 +8,10 @@ travels over that channel, and every rank opens a communicator on the RCCL C API
 The bucket reducer (``GradBucketReducer(rccl_comm=...)``) and the pipeline's send/recv can then run on it
 without going through c10d.
 
-Selection: ``PDT_COMM=rccl`` (or ``Engine(comm_backend="rccl")``) - the default stays c10d's "nccl" backend,
-which drives the same RCCL library.
+Selection: the framework's communicator is the default on GPUs with one rank per device; ``PDT_COMM=c10d`` (or
+``Engine(comm_backend="c10d")`` / ``--comm-backend c10d``) routes the same traffic through torch's "nccl" process
+group instead, which drives the same RCCL library.  CPU runs and rehearsals with several ranks on one GPU always
+use the gloo process group.
 """
 from __future__ import annotations
 
@@ -27,8 +29,8 @@ _LOCK = threading.Lock()  # held by the watchdog's poll and by close_all()
 
 
 def backend_choice(explicit: Optional[str] = None) -> str:
-    """"c10d" or "rccl" (from the argument, else the PDT_COMM environment variable)."""
-    choice = (explicit or os.environ.get("PDT_COMM") or "c10d").lower()
+    """"rccl" (default) or "c10d" (from the argument, else the PDT_COMM environment variable)."""
+    choice = (explicit or os.environ.get("PDT_COMM") or "rccl").lower()
     if choice not in ("c10d", "rccl"):
         raise ValueError(f"unknown communication backend {choice!r} (c10d | rccl)")
     return choice

@@ -96,21 +96,28 @@ class _PyReducer:
 
 def make_reducer(pg, arena: ParamArena, expected: List[int], average: bool = True, comm_dtype: Optional[torch.dtype] = None,
                  comm_backend: Optional[str] = None):
-    """The C++ bucket reducer over `pg` (c10d: "nccl" = RCCL, or gloo) or, with ``comm_backend="rccl"`` /
-    ``PDT_COMM=rccl`` on a GPU, over this framework's own RCCL communicator spanning the same ranks."""
+    """The C++ bucket reducer over this framework's own RCCL communicator spanning the ranks of `pg` (GPU runs with
+    one rank per device; the default) or over `pg` itself (``comm_backend="c10d"`` / ``PDT_COMM=c10d``: torch's
+    "nccl" = RCCL group; always for gloo groups).  The reducer carries ``backend_label`` ("rccl", "c10d:nccl",
+    "c10d:gloo") and ``rccl_comm`` (the RcclComm or None)."""
     code = {None: 0, torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[comm_dtype]
     from ..ops import available, native
     from .comm import backend_choice, create_rccl_comm
 
+    label = "c10d:" + (dist.get_backend(pg) if dist.is_initialized() else "none")
     if available():
+        comm = None
         if backend_choice(comm_backend) == "rccl" and arena.device.type == "cuda" and (
                 not dist.is_initialized() or dist.get_backend(pg) == "nccl"):
             comm = create_rccl_comm(None if pg is dist.group.WORLD else pg, arena.device)
-            return native().GradBucketReducer(comm, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
-        return native().GradBucketReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+            red = native().GradBucketReducer(comm, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+            label = "rccl"
+        else:
+            red = native().GradBucketReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+        return red, label, comm
     if arena.device.type == "cuda":
         native()  # raises with the build hint: never fall back silently on a GPU box
-    return _PyReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
+    return _PyReducer(pg, arena.grad, list(arena.bucket_bounds), list(expected), average, code), label, None
 
 
 class DataParallel(nn.Module):
@@ -147,7 +154,8 @@ class DataParallel(nn.Module):
                         expected[seg.bucket] += 1
                         p.register_post_accumulate_grad_hook(self._make_hook(seg.bucket))
             expected = [max(1, e) for e in expected]
-        self.reducer = make_reducer(self.pg, arena, expected, True, comm_dtype, comm_backend)
+        self.reducer, self.backend_label, self.rccl_comm = make_reducer(self.pg, arena, expected, True, comm_dtype,
+                                                                        comm_backend)
         if self.world_size > 1:
             self._verify_replicas()
         if broadcast_from is not None and self.world_size > 1:
@@ -172,6 +180,13 @@ class DataParallel(nn.Module):
             raise RuntimeError(f"data-parallel replicas differ: ranks {bad} do not match rank 0 "
                                f"(arena elements / parameters / buckets / layout hash: "
                                f"{[t.tolist() for t in every]})")
+
+    def rccl_ranks(self) -> int:
+        """Ranks that exchange this model's gradients over RCCL: what RCCL itself reports for the framework's own
+        communicator (ncclCommCount), the group size for torch's "nccl" group, 0 for gloo."""
+        if self.rccl_comm is not None:
+            return int(self.rccl_comm.comm_count())
+        return self.world_size if self.backend_label == "c10d:nccl" else 0
 
     def check_replicas(self) -> None:
         """Raise unless every rank of the group holds bit-identical master parameters (host sync; collective).

@@ -214,7 +214,8 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     from ..optim import AdamW, get_linear_schedule_with_warmup
     from ..recipes import _collator, build_datasets
     from ..utils.logging import StepLogger
-    from ..utils.seed import set_seed
+    from ..utils.seed import seed_step, set_seed
+    from ..utils.watchdog import StepWatchdog, inject_fault
 
     if cfg.mp_layout == "towers":
         from ..models.tribert import run_tower_training
@@ -253,20 +254,42 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     log_rank = mesh.is_last_stage and engine.is_main_process
     logger = StepLogger(log_rank, cfg.log_every, cfg.log_file, samples_per_step=micro_bs * accum * mesh.dp)
     suffix = f"stage{mesh.stage}"
-    start_epoch, global_step = 0, 0
-    if cfg.output_dir and ckpt.has_checkpoint(cfg.output_dir, suffix):
-        extra = ckpt.load_training_state(cfg.output_dir, stage_model, optimizer, sched, suffix)
+    start_epoch, global_step, start_batch = 0, 0, 0
+    resume_dir = cfg.resume or cfg.output_dir
+    # the two stages publish their checkpoints one after the other: resume from the newest one BOTH completed
+    tag = ckpt.common_tag(resume_dir, suffix) if resume_dir else None
+    if tag is not None:
+        extra = ckpt.load_training_state(resume_dir, stage_model, optimizer, sched, suffix, tag=tag)
         start_epoch, global_step = int(extra.get("epoch", 0)), int(extra.get("global_step", 0))
+        start_batch = int(extra.get("micro_offset", 0))
+        engine.print(f"resumed from {resume_dir}/checkpoint-{tag}: epoch {start_epoch}, batch {start_batch}")
+    dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), rank)
+    seed_step(cfg.seed, rank, global_step)
+
+    def save(epoch: int, offset: int) -> None:
+        if cfg.output_dir and engine.is_main_process:  # data-parallel rank 0 of each stage writes its part
+            ckpt.save_training_state(cfg.output_dir, stage_model, optimizer, sched,
+                                     {"epoch": epoch, "global_step": global_step, "micro_offset": offset}, suffix,
+                                     write_config=mesh.stage == 0)
+
     losses: List[float] = []
     result: dict = {}
     t0 = time.perf_counter()
     done = False
     for epoch in range(start_epoch, cfg.num_epochs):
         train_dl.set_epoch(epoch)
-        for batch in train_dl:
+        first = start_batch if epoch == start_epoch else 0
+        if first:
+            train_dl.skip_batches(first)
+        for index, batch in enumerate(train_dl, start=first):
             loss = pipe.train_step(batch)
             pipe.optimizer_step(optimizer, sched)
             global_step += 1
+            seed_step(cfg.seed, rank, global_step)
+            dog.heartbeat()
+            if cfg.save_every and global_step % cfg.save_every == 0:
+                save(epoch, index + 1)
+            inject_fault(rank, global_step)
             if loss is not None:
                 record = global_step % cfg.log_every == 0 or bool(cfg.max_steps)
                 if record and mesh.dp > 1:
@@ -287,12 +310,11 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
                 metric.add_batch(predictions=preds, references=refs, valid=valid)
         result = metric.compute() if mesh.is_last_stage else {}
         logger.log_epoch(epoch, result)
-        if cfg.output_dir and engine.is_main_process:
-            ckpt.save_training_state(cfg.output_dir, stage_model, optimizer, sched,
-                                     {"epoch": epoch + 1, "global_step": global_step}, suffix)
+        save(epoch + 1, 0)
         dist.barrier()
         if done:
             break
+    dog.close()
     replicas_equal = None
     if pipe.dp is not None:
         pipe.dp.check_replicas()  # raises if a gradient ever missed its reduction

@@ -41,7 +41,7 @@ from .models.config import preset
 from .optim import AdamW, get_linear_schedule_with_warmup
 from .utils.logging import StepLogger
 from .utils.profile import trace_range
-from .utils.seed import set_seed
+from .utils.seed import seed_step, set_seed
 from .utils.watchdog import StepWatchdog, inject_fault
 
 
@@ -130,6 +130,7 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
         start_micro = int(extra.get("micro_offset", 0))
         engine.print(f"resumed from {resume_dir}: epoch {start_epoch}, batch {start_micro}, optimizer step {global_step}")
 
+    seed_step(cfg.seed, engine.process_index, global_step)
     logger = StepLogger(engine.is_main_process, cfg.log_every, cfg.log_file,
                         samples_per_step=micro_bs * accum * engine.num_processes)
     dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), engine.process_index)
@@ -172,12 +173,13 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                     optimizer.zero_grad()
                 pending = 0
                 global_step += 1
+                seed_step(cfg.seed, engine.process_index, global_step)
                 dog.heartbeat()
-                inject_fault(engine.process_index, global_step)
                 logger.log_step(global_step, loss * window, lr_scheduler.get_last_lr()[0], engine.scaler, comm_extra)
                 if cfg.save_every and cfg.output_dir and global_step % cfg.save_every == 0 and engine.is_main_process:
                     ckpt.save_training_state(cfg.output_dir, model, optimizer, lr_scheduler,
                                              {"epoch": epoch, "global_step": global_step, "micro_offset": step + 1})
+                inject_fault(engine.process_index, global_step)
                 if cfg.max_steps and global_step >= cfg.max_steps:
                     done = True
                     break
@@ -191,6 +193,8 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
             break
     dog.close()
     logger.close()
+    if cfg.output_dir and engine.is_main_process:
+        ckpt.save_pretrained(model, cfg.output_dir)  # the trained model as an HF directory (config.json + safetensors)
     if hasattr(model, "check_replicas"):
         model.check_replicas()  # raises if a gradient ever missed its reduction
         last_metric["replicas_bit_equal"] = True

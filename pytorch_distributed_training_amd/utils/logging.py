@@ -5,6 +5,7 @@ Loss values are fetched from the device only every ``every`` steps, so logging a
 from __future__ import annotations
 
 import json
+import os
 import time
 from typing import Optional
 
@@ -15,6 +16,8 @@ class StepLogger:
     def __init__(self, is_main: bool, every: int = 10, path: Optional[str] = None, samples_per_step: int = 0,
                  tokens_per_step: int = 0):
         self.is_main, self.every = is_main, max(1, every)
+        if path and is_main and os.path.dirname(path):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
         self.file = open(path, "a") if (path and is_main) else None
         self.samples_per_step, self.tokens_per_step = samples_per_step, tokens_per_step
         self.t_last, self.step_last = time.perf_counter(), 0

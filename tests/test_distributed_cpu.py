@@ -59,7 +59,14 @@ def test_data_parallel_recipe_two_ranks(tmp_path):
     res = run_distributed(W.dp_recipe, 2, args=(str(tmp_path),))
     assert res[0]["optimizer_steps"] == res[1]["optimizer_steps"] == 4
     assert res[0]["accuracy"] == res[1]["accuracy"]
-    assert os.path.exists(tmp_path / "model.safetensors") and os.path.exists(tmp_path / "training_state.pt")
+    # the trained model as an HF directory + the newest training-state checkpoint, published through latest.json
+    assert os.path.exists(tmp_path / "model.safetensors") and os.path.exists(tmp_path / "config.json")
+    from pytorch_distributed_training_amd import checkpoint as ck
+
+    tag = ck.latest_tag(str(tmp_path))
+    assert tag == "00000004-2-0" and os.path.exists(tmp_path / f"checkpoint-{tag}" / "training_state.pt")
+    assert ck.available_tags(str(tmp_path)) == ["00000002-1-0", tag]  # the last two are kept
+    assert res[0]["replicas_bit_equal"] and res[1]["replicas_bit_equal"]
 
 
 def test_debug_mode_guards_and_exposed_comm_timer():

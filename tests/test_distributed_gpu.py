@@ -168,7 +168,8 @@ def grads(mode):
     m.train()
     red = None
     if mode is not None:
-        red = make_reducer(None, arena, list(arena.bucket_segments), True, mode[1], comm_backend="rccl")
+        red, label, _ = make_reducer(None, arena, list(arena.bucket_segments), True, mode[1], comm_backend="rccl")
+        assert label == "rccl"
         seg_bucket = [s.bucket for s in arena.segments]
         m.runtime.segment_done = lambda seg: red.mark_ready(seg_bucket[seg], 1)
         red.begin(True)

@@ -311,3 +311,30 @@ def test_data_parallel_recipe_end_to_end_single_gpu(tmp_path):
     assert 0.0 <= out["accuracy"] <= 1.0 and 0.0 <= out["f1"] <= 1.0
     again = run_data_parallel(cfg)
     assert again["optimizer_steps"] == 16  # resumed at the end of the last epoch: no further steps
+
+
+def test_segment_outside_the_graph_contributes_zero_gradient():
+    """zero_grad() does not memset slices whose native producer overwrites them; a layer that takes no part in a
+    step (here: the forward stops after layer 0) must still count as zero gradient, not as last step's values."""
+    from pytorch_distributed_training_amd.optim import FusedAdamW
+
+    ref, nat, arena = _pair("bert-tiny", torch.float16)
+    opt = FusedAdamW(arena, lr=1e-2)
+    batch = _batch(ref.config)
+    nat.train()
+    nat(**batch).loss.backward()          # every segment written
+    opt.step(); opt.zero_grad()
+    last = nat.bert.encoder.layers()[-1]
+    seg = arena.segments[last._native.segment]
+    before = arena.master[seg.start:seg.end].clone()
+    assert arena.grad[seg.start:seg.end].abs().sum() > 0   # stale values are still there (no memset)
+    # a step whose graph skips the last layer: embeddings -> layer 0 -> head
+    nat._begin_forward()
+    x = nat.bert.embeddings(batch["input_ids"], batch["token_type_ids"])
+    from pytorch_distributed_training_amd.models.bert import MaskInfo
+
+    x = nat.bert.encoder.layers()[0](x, MaskInfo(batch["attention_mask"], *batch["input_ids"].shape, x.device))
+    nat.head(x, batch["labels"]).loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(arena.master[seg.start:seg.end], before)

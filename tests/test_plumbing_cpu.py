@@ -396,7 +396,7 @@ def test_comm_backend_choice_and_flag(monkeypatch):
     from pytorch_distributed_training_amd.utils.watchdog import poll_comm_errors
 
     monkeypatch.delenv("PDT_COMM", raising=False)
-    assert backend_choice() == "c10d" and backend_choice("rccl") == "rccl"
+    assert backend_choice() == "rccl" and backend_choice("c10d") == "c10d"
     monkeypatch.setenv("PDT_COMM", "rccl")
     assert backend_choice() == "rccl" and backend_choice("c10d") == "c10d"
     with pytest.raises(ValueError):
