@@ -112,7 +112,8 @@ def main() -> None:
     model.train()
     micro = args.batch // args.accum
     vocab = eng.unwrap_model(model).config.vocab_size
-    pool = [fixed_batch(micro, args.seq_len, vocab, eng.device, seed=1000 * eng.process_index + i) for i in range(4)]
+    pool = [fixed_batch(micro, args.seq_len, vocab, eng.device, seed=1000 * eng.process_index + i,
+                        first_id=eng.process_index * args.batch + (i % args.accum) * micro) for i in range(4)]
 
     def step(i: int) -> torch.Tensor:
         loss = None
@@ -262,8 +263,8 @@ def bench_pipeline(args, world: int, comm) -> None:
     pipe = PipelineStage(stage, mesh, eng, micro_batches=args.micro_batches)
     replica_batch = 2 * args.batch
     # both stage ranks of a replica read the same batches (only hidden states cross the link)
-    pool = [fixed_batch(replica_batch, args.seq_len, model_cfg.vocab_size, eng.device, seed=1000 * mesh.replica + i)
-            for i in range(4)]
+    pool = [fixed_batch(replica_batch, args.seq_len, model_cfg.vocab_size, eng.device, seed=1000 * mesh.replica + i,
+                        first_id=mesh.replica * replica_batch) for i in range(4)]
     loss = None
 
     def step(i: int):

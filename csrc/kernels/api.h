@@ -14,8 +14,16 @@ enum { PDT_F16 = 0, PDT_BF16 = 1 };
 
 typedef struct PdtRng {
   const uint64_t* state;  // device memory: state[0] = seed, state[1] = optimizer-step offset
-  uint32_t micro;         // micro-batch index inside the step
+  uint32_t micro;         // micro-batch counter (or, with sample ids, the optimizer-step counter)
   uint32_t stream;        // dropout site id
+  // Optional global sample ids (device, int32 [B]).  When given, the dropout counters of row r of a [B*seq, H]
+  // activation are derived from (sample_ids[r / seq], r % seq) instead of r, those of a [B, H] tensor from
+  // sample_ids[b], and the attention masks from (sample_ids[b], head, query, key): a mask then belongs to the
+  // SAMPLE, whichever rank, micro-batch or padded length the sample is processed with - data-parallel and
+  // pipelined runs draw exactly the masks of a single-GPU run over the same global batch.
+  const int32_t* sample_ids;
+  uint32_t seq;           // tokens per sample of the activation the kernel works on (1 for [B, H] tensors)
+  uint32_t seq_magic;     // ceil(2^32 / seq): row / seq == umulhi(row, seq_magic) for row * seq < 2^32
 } PdtRng;
 
 // ---- GEMM -------------------------------------------------------------------------------------
@@ -110,8 +118,9 @@ int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_
 // (finish with pdt_colsum_finish, nseg = R)
 int pdt_embed_type_partial(int dtype, const void* d, const int64_t* type_ids, float* partial, int* nblk, int tokens,
                            int H, int R, void* stream);
-// apply the dropout mask of `rng` to a 16-bit [n] tensor: y = keep ? x*scale : 0
-int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, float drop_scale, uint32_t drop_thr,
+// apply the dropout mask of `rng` to a 16-bit [n / H, H] tensor: y = keep ? x*scale : 0 (the mask the embedding
+// forward drew for the same rng)
+int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, int H, float drop_scale, uint32_t drop_thr,
                       PdtRng rng, void* stream);
 
 // ---- Attention -------------------------------------------------------------------------------------

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const int q = q0 + lm, qc = min(q, S - 1);
   const short8 qf0 = gfrag<T>(base, qc, ld, 0, lane), qf1 = gfrag<T>(base, qc, ld, 1, lane);
   const float k2 = a.scale * LOG2E;
-  const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
+  const uint32_t rseed = attn_row_seed(drop_key(a.rng), drop_sample(a.rng, b) * a.A + h, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   const bool drop = a.drop_thr != 0;
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   const float k2 = a.scale * LOG2E;
   // exp2(score2 + mask - lse2q) = p * scale; rows >= S get lse = +inf, i.e. p = 0 and a zero dQ row
   const float lse2q = (q < S ? a.lse[(size_t)bh * S + qc] * LOG2E : INFINITY) - __log2f(a.scale);
-  const uint32_t rseed = attn_row_seed(drop_key(a.rng), bh, q), thr_hi = attn_thr_hi(a.drop_thr);
+  const uint32_t rseed = attn_row_seed(drop_key(a.rng), drop_sample(a.rng, b) * a.A + h, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   const bool drop = a.drop_thr != 0;
   float4v dq[4];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
       // log2-domain lse, +inf for the padding rows (p = 0); delta pre-multiplied by -scale
       lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] * LOG2E : INFINITY;
       del_s[i] = i < S ? -a.scale * a.delta[(size_t)bh * S + i] : 0.f;
-      seed_s[i] = attn_row_seed(dk, bh, i);
+      seed_s[i] = attn_row_seed(dk, drop_sample(a.rng, b) * a.A + h, i);
     }
     const short8 kf0 = gfrag<T>(base + a.H, kc, ld, 0, lane), kf1 = gfrag<T>(base + a.H, kc, ld, 1, lane);
     const short8 vf0 = gfrag<T>(base + 2 * a.H, kc, ld, 0, lane), vf1 = gfrag<T>(base + 2 * a.H, kc, ld, 1, lane);
@@ -520,7 +520,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
       mbias[tid] = (tid < S && mask_raw != 0) ? 0.f : -INFINITY;
       // log2-domain lse; +inf for the padding rows makes their recomputed probabilities exactly 0
       lse_s[tid] = tid < S ? lse_raw * LOG2E : INFINITY;
-      seed_s[tid] = attn_row_seed(dk, bh, tid);
+      seed_s[tid] = attn_row_seed(dk, drop_sample(a.rng, b) * a.A + h, tid);
     }
     float d = 0.f;
 #pragma unroll

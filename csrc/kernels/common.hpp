@@ -131,6 +131,16 @@ __device__ __forceinline__ DropKey drop_key(const RngArgs& r) {
   k.micro = r.micro;
   return k;
 }
+// Row of a [B*seq, H] activation -> the row its dropout counters are derived from (see PdtRng::sample_ids):
+// global sample id * 512 + position inside the sample (512 = the longest sequence the position table allows).
+__device__ __forceinline__ uint32_t drop_row(const RngArgs& r, uint32_t row) {
+  if (!r.sample_ids) return row;
+  const uint32_t b = __umulhi(row, r.seq_magic);
+  return (uint32_t)r.sample_ids[b] * 512u + (row - b * r.seq);
+}
+__device__ __forceinline__ uint32_t drop_sample(const RngArgs& r, uint32_t b) {
+  return r.sample_ids ? (uint32_t)r.sample_ids[b] : b;
+}
 // keep-bits for the 8 elements of group `g` (element index / 8): bit i set => element kept.
 // thr16 = round(p * 65536): an element is dropped when its 16-bit draw is < thr16.
 __device__ __forceinline__ uint32_t drop_keep8(const DropKey& k, uint64_t g, uint32_t thr16) {

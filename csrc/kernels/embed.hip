@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       if (drop_thr != 0) {
-        const uint32_t keep = drop_keep8(dk, ((uint64_t)tok * H + c * 8) >> 3, drop_thr);
+        const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_row(rng, tok) * H + c * 8) >> 3, drop_thr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? o[j] * drop_scale : 0.f;
       }

@@ -165,7 +165,7 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] *= d[i];
     }
     if (epi == EPI_BIAS_DROP_RES && g.drop_thr != 0) {
-      const uint32_t keep = drop_keep8(dk, ((uint64_t)m * g.N + n) >> 3, g.drop_thr);
+      const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_row(g.rng, m) * g.N + n) >> 3, g.drop_thr);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * g.drop_scale : 0.0f;
     }

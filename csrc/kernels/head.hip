@@ -25,7 +25,7 @@ __global__ __launch_bounds__(HEAD_FWD_WAVES * 64) void head_fwd_kernel(const T* 
       float x[8];
       unpack8<T>(*reinterpret_cast<const short8*>(pooled + (size_t)b * H + ch * 8), x);
       if (drop_thr != 0) {
-        const uint32_t keep = drop_keep8(dk, ((uint64_t)b * H + ch * 8) >> 3, drop_thr);
+        const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_sample(rng, b) * H + ch * 8) >> 3, drop_thr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = ((keep >> j) & 1u) ? x[j] * drop_scale : 0.f;
       }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ poo
     const float x = Half16<T>::to_f(reinterpret_cast<const short*>(pooled)[(size_t)b * H + h]);
     float keepscale = 1.f;
     if (drop_thr != 0) {
-      const uint32_t keep = drop_keep8(dk, ((uint64_t)b * H + h) >> 3, drop_thr);
+      const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_sample(rng, b) * H + h) >> 3, drop_thr);
       keepscale = ((keep >> (h & 7)) & 1u) ? drop_scale : 0.f;
     }
     float dp = 0.f;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         *reinterpret_cast<short8*>(dx + (size_t)row * H + c * 8) = pack8<T>(o);
         if (ddrop) {
           if (drop_thr != 0) {
-            const uint32_t keep = drop_keep8(dk, ((uint64_t)row * H + c * 8) >> 3, drop_thr);
+            const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_row(rng, row) * H + c * 8) >> 3, drop_thr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? o[j] * drop_scale : 0.f;
           }
@@ -200,14 +200,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n8,
-                                                            float scale, uint32_t thr, RngArgs rng) {
+                                                            int H, float scale, uint32_t thr, RngArgs rng) {
   DropKey dk = drop_key(rng);
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
     float v[8];
     unpack8<T>(reinterpret_cast<const short8*>(x)[i], v);
     if (thr != 0) {
-      const uint32_t keep = drop_keep8(dk, (uint64_t)i, thr);
+      // the counters of element (row, col) of the [rows, H] tensor, as every other kernel derives them
+      const uint32_t row = (uint32_t)((i * 8) / H);
+      const uint64_t grp = ((uint64_t)drop_row(rng, row) * H + (uint64_t)(i * 8 - (int64_t)row * H)) >> 3;
+      const uint32_t keep = drop_keep8(dk, grp, thr);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = ((keep >> j) & 1u) ? v[j] * scale : 0.f;
     }
@@ -291,17 +294,17 @@ extern "C" int pdt_colsum_partial(int dtype, const void* x, int rows, int ncols,
   return (int)hipGetLastError();
 }
 
-extern "C" int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, float drop_scale, uint32_t drop_thr,
-                                 PdtRng rng, void* stream) {
-  if (n & 7) return -3;
+extern "C" int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, int H, float drop_scale,
+                                 uint32_t drop_thr, PdtRng rng, void* stream) {
+  if ((n & 7) || H <= 0 || (H & 7) || n % H) return -3;
   const int64_t n8 = n >> 3;
   int grid = (int)((n8 + 255) / 256);
   grid = grid > 2048 ? 2048 : (grid < 1 ? 1 : grid);
   if (dtype == PDT_F16)
     hipLaunchKernelGGL(dropout_apply_kernel<_Float16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)x, (_Float16*)y, n8, drop_scale, drop_thr, rng);
+                       (const _Float16*)x, (_Float16*)y, n8, H, drop_scale, drop_thr, rng);
   else
     hipLaunchKernelGGL(dropout_apply_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x,
-                       (__bf16*)y, n8, drop_scale, drop_thr, rng);
+                       (__bf16*)y, n8, H, drop_scale, drop_thr, rng);
   return (int)hipGetLastError();
 }

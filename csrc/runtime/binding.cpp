@@ -115,9 +115,24 @@ void chkf32(const Tensor& t, const char* name) {
 uint32_t thr16(double p) { return p <= 0.0 ? 0u : (uint32_t)std::lround(p * 65536.0); }
 float keep_scale(double p) { return p <= 0.0 ? 1.0f : (float)(1.0 / (1.0 - p)); }
 
-PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site) {
+using OptTensor = c10::optional<Tensor>;
+// `sids` (optional int32 [B] on the GPU): global sample ids - the dropout counters of row r of a [B*seq, H]
+// activation then derive from (sids[r / seq], r % seq), see PdtRng in api.h.
+PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site, const OptTensor& sids = c10::nullopt, int64_t seq = 1,
+                int64_t batch = -1) {
   TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kLong && state.numel() >= 2, "rng state: int64[2] on GPU");
-  return PdtRng{reinterpret_cast<const uint64_t*>(state.data_ptr<int64_t>()), (uint32_t)micro, (uint32_t)site};
+  PdtRng r{reinterpret_cast<const uint64_t*>(state.data_ptr<int64_t>()), (uint32_t)micro, (uint32_t)site, nullptr, 1u, 0u};
+  if (sids.has_value()) {
+    TORCH_CHECK(sids->is_cuda() && sids->scalar_type() == at::kInt && sids->is_contiguous() && sids->dim() == 1,
+                "sample_ids must be a contiguous int32 [B] GPU tensor");
+    TORCH_CHECK(seq >= 1 && seq <= 512, "sample-keyed dropout: at most 512 tokens per sample");
+    TORCH_CHECK(batch < 0 || sids->numel() == batch, "sample_ids has ", sids->numel(), " entries for a batch of ", batch);
+    TORCH_CHECK(sids->numel() * seq < (int64_t(1) << 23), "sample-keyed dropout: too many rows for the exact row / seq trick");
+    r.sample_ids = sids->data_ptr<int32_t>();
+    r.seq = (uint32_t)seq;
+    r.seq_magic = seq == 1 ? 0u : (uint32_t)(((uint64_t(1) << 32) + (uint64_t)seq - 1) / (uint64_t)seq);
+  }
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -255,7 +270,8 @@ struct LayerDims { int B, S, A; double p_attn, p_hidden, eps; int64_t micro, lay
 
 std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Tensor& kv_len,
                                   const std::vector<Tensor>& w, const Tensor& rng_state, int64_t B, int64_t S, int64_t A,
-                                  double p_attn, double p_hidden, double eps, int64_t micro, int64_t layer) {
+                                  double p_attn, double p_hidden, double eps, int64_t micro, int64_t layer,
+                                  const OptTensor& sids) {
   DeviceGuard guard(x.device());
   chk16(x, "x");
   TORCH_CHECK(w.size() == 12, "layer_forward: 12 weight tensors expected");
@@ -271,10 +287,10 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
   Tensor lse = at::empty({B, A, S}, f32);
   check(pdt_attn_fwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
                      lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p_attn), thr16(p_attn),
-                     make_rng(rng_state, micro, site + 0), cur_stream()), "attn_fwd");
+                     make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()), "attn_fwd");
 
   Epi e_ao; e_ao.kind = PDT_EPI_BIAS_DROP_RES; e_ao.bias = &w[3]; e_ao.res = &x; e_ao.drop_p = p_hidden;
-  e_ao.rng = make_rng(rng_state, micro, site + 1);
+  e_ao.rng = make_rng(rng_state, micro, site + 1, sids, S, B);
   Tensor z1 = gemm_nt(ctx, w[2], e_ao);
   Tensor stats1 = at::empty({T, 2}, f32);
   Tensor x1 = ln_fwd(z1, w[4], w[5], stats1, eps);
@@ -284,7 +300,7 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
   Tensor gact = gemm_nt(x1, w[6], e_f1);
 
   Epi e_f2; e_f2.kind = PDT_EPI_BIAS_DROP_RES; e_f2.bias = &w[9]; e_f2.res = &x1; e_f2.drop_p = p_hidden;
-  e_f2.rng = make_rng(rng_state, micro, site + 2);
+  e_f2.rng = make_rng(rng_state, micro, site + 2, sids, S, B);
   Tensor z2 = gemm_nt(gact, w[8], e_f2);
   Tensor stats2 = at::empty({T, 2}, f32);
   Tensor x2 = ln_fwd(z2, w[10], w[11], stats2, eps);
@@ -294,7 +310,7 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
 Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Tensor>& sv, const Tensor& mask,
                       const Tensor& kv_len, const std::vector<Tensor>& w, std::vector<Tensor> gr,
                       const Tensor& rng_state, int64_t B, int64_t S, int64_t A, double p_attn, double p_hidden,
-                      int64_t micro, int64_t layer, bool accumulate) {
+                      int64_t micro, int64_t layer, bool accumulate, const OptTensor& sids) {
   DeviceGuard guard(x.device());
   TORCH_CHECK(sv.size() == 10 && w.size() == 12 && gr.size() == 12, "layer_backward: bad list sizes");
   const Tensor dy = dy_in.contiguous();
@@ -305,7 +321,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   const int64_t site = layer * 4;
 
   // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
-  LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2),
+  LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2, sids, S, B),
                        accumulate);
   // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU) ; wgrad
   Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
@@ -318,7 +334,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   lane.run([&] { gemm_tn_into(du, x1, gr[6], accumulate); });
   Tensor dx1 = gemm_nn(du, w[6], e_add);
   // LN1
-  LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1),
+  LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1, sids, S, B),
                        accumulate);
   // attention output projection
   lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); });
@@ -332,7 +348,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
                      dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
                      fused_db ? db_part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
-                     thr16(p_attn), make_rng(rng_state, micro, site + 0), cur_stream()),
+                     thr16(p_attn), make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()),
         "attn_bwd");
   if (fused_db)
     check(pdt_colsum_finish(db_part.data_ptr<float>(), (int)B, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, nullptr,
@@ -354,10 +370,11 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
 std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor& pos_ids, const Tensor& type_ids,
                                   const c10::optional<Tensor>& inputs_embeds, const Tensor& word, const Tensor& pos,
                                   const Tensor& type, const Tensor& gamma, const Tensor& beta, const Tensor& rng_state,
-                                  double eps, double p, int64_t micro, int64_t site) {
+                                  double eps, double p, int64_t micro, int64_t site, const OptTensor& sids, int64_t seq) {
   DeviceGuard guard(word.device());
   const int H = (int)word.size(1);
   const int tokens = (int)pos_ids.numel();
+  TORCH_CHECK(seq >= 1 && tokens % seq == 0, "embed_forward: tokens must be a multiple of the sequence length");
   Tensor pre = at::empty({tokens, H}, word.options());
   Tensor y = at::empty({tokens, H}, word.options());
   Tensor stats = at::empty({tokens, 2}, word.options().dtype(at::kFloat));
@@ -368,7 +385,7 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
                       word.data_ptr(), pos.data_ptr(), type.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                       pre.data_ptr(), y.data_ptr(), stats.data_ptr<float>(), tokens, H, (int)word.size(0), (int)pos.size(0),
                       (int)type.size(0), (float)eps, keep_scale(p),
-                      thr16(p), make_rng(rng_state, micro, site), cur_stream()), "embed_fwd");
+                      thr16(p), make_rng(rng_state, micro, site, sids, seq, tokens / seq), cur_stream()), "embed_fwd");
   return {y, pre, stats};
 }
 
@@ -376,7 +393,8 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
 // embedding (needed only when the caller fed inputs_embeds and wants its gradient).
 Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stats, const c10::optional<Tensor>& ids,
                       const Tensor& pos_ids, const Tensor& type_ids, const Tensor& gamma, std::vector<Tensor> gr,
-                      const Tensor& rng_state, double p, int64_t micro, int64_t site, int64_t pad_id, bool accumulate) {
+                      const Tensor& rng_state, double p, int64_t micro, int64_t site, int64_t pad_id, bool accumulate,
+                      const OptTensor& sids, int64_t seq) {
   DeviceGuard guard(pre.device());
   TORCH_CHECK(gr.size() == 5, "embed_backward: 5 gradient tensors expected");
   const Tensor dy = dy_in.contiguous();
@@ -384,8 +402,8 @@ Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stat
   Tensor dmask = dy;
   if (p > 0.0) {
     dmask = at::empty_like(dy);
-    check(pdt_dropout_apply(dt_code(dy), dy.data_ptr(), dmask.data_ptr(), dy.numel(), keep_scale(p), thr16(p),
-                            make_rng(rng_state, micro, site), cur_stream()), "dropout_apply");
+    check(pdt_dropout_apply(dt_code(dy), dy.data_ptr(), dmask.data_ptr(), dy.numel(), H, keep_scale(p), thr16(p),
+                            make_rng(rng_state, micro, site, sids, seq, tokens / seq), cur_stream()), "dropout_apply");
   }
   LnBwdOut l = ln_bwd(dmask, pre, stats, gamma, &gr[3], &gr[4], nullptr, 0.0, make_rng(rng_state, micro, site),
                       accumulate);
@@ -428,7 +446,7 @@ Tensor dense_backward(const Tensor& dpre, const Tensor& first_tok, const Tensor&
 
 std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Tensor& bias,
                                  const c10::optional<Tensor>& labels, const Tensor& rng_state, double p, int64_t micro,
-                                 int64_t site) {
+                                 int64_t site, const OptTensor& sids) {
   DeviceGuard guard(pooled.device());
   chk16(pooled, "pooled"); chkf32(W, "W"); chkf32(bias, "bias");
   const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
@@ -441,14 +459,15 @@ std::vector<Tensor> head_forward(const Tensor& pooled, const Tensor& W, const Te
   Tensor loss = at::zeros({}, f32);
   check(pdt_head_fwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), bias.data_ptr<float>(),
                      labels.has_value() ? labels->data_ptr<int64_t>() : nullptr, logits.data_ptr<float>(),
-                     loss.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site),
+                     loss.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site, sids, 1, B),
                      cur_stream()), "head_fwd");
   return {logits, loss};
 }
 
 Tensor head_backward(const c10::optional<Tensor>& gloss, const c10::optional<Tensor>& dlogits, const Tensor& pooled,
                      const Tensor& W, const Tensor& logits, const c10::optional<Tensor>& labels, Tensor gW, Tensor gb,
-                     const Tensor& rng_state, double p, int64_t micro, int64_t site, bool accumulate, bool tanh_bwd) {
+                     const Tensor& rng_state, double p, int64_t micro, int64_t site, bool accumulate, bool tanh_bwd,
+                     const OptTensor& sids) {
   DeviceGuard guard(pooled.device());
   const int B = (int)pooled.size(0), H = (int)pooled.size(1), C = (int)W.size(0);
   Tensor gl, dl;
@@ -459,17 +478,19 @@ Tensor head_backward(const c10::optional<Tensor>& gloss, const c10::optional<Ten
   check(pdt_head_bwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), logits.data_ptr<float>(),
                      ce ? labels->data_ptr<int64_t>() : nullptr, ce ? gl.data_ptr<float>() : nullptr,
                      dl.defined() ? dl.data_ptr<float>() : nullptr, dpooled.data_ptr(), gW.data_ptr<float>(),
-                     gb.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site),
+                     gb.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site, sids, 1, B),
                      accumulate ? 1 : 0, tanh_bwd ? 1 : 0, cur_stream()), "head_bwd");
   return dpooled;
 }
 
-Tensor dropout16(const Tensor& x, const Tensor& rng_state, double p, int64_t micro, int64_t site) {
+// x: [B, H] (one row per sample)
+Tensor dropout16(const Tensor& x, const Tensor& rng_state, double p, int64_t micro, int64_t site, const OptTensor& sids) {
   DeviceGuard guard(x.device());
   Tensor xc = x.contiguous();
   Tensor y = at::empty_like(xc);
-  check(pdt_dropout_apply(dt_code(xc), xc.data_ptr(), y.data_ptr(), xc.numel(), keep_scale(p), thr16(p),
-                          make_rng(rng_state, micro, site), cur_stream()), "dropout_apply");
+  TORCH_CHECK(xc.dim() == 2, "dropout16 expects a [B, H] tensor");
+  check(pdt_dropout_apply(dt_code(xc), xc.data_ptr(), y.data_ptr(), xc.numel(), (int)xc.size(1), keep_scale(p), thr16(p),
+                          make_rng(rng_state, micro, site, sids, 1, xc.size(0)), cur_stream()), "dropout_apply");
   return y;
 }
 
@@ -517,14 +538,14 @@ void cast_to_16(const Tensor& src, Tensor dst) {
 Tensor op_gemm(const std::string& layout, const Tensor& A, const Tensor& B, int64_t epi,
                const c10::optional<Tensor>& bias, const c10::optional<Tensor>& res, c10::optional<Tensor> aux,
                const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site, int64_t tile,
-               c10::optional<Tensor> colsum) {
+               c10::optional<Tensor> colsum, const OptTensor& sids, int64_t seq) {
   DeviceGuard guard(A.device());
   Epi e; e.kind = (int)epi; e.drop_p = drop_p;
   if (colsum.has_value()) e.colsum = &*colsum;  // adds to the tensor's content
   if (bias.has_value()) e.bias = &*bias;
   if (res.has_value()) e.res = &*res;
   if (aux.has_value()) e.aux = &*aux;
-  if (rng_state.has_value()) e.rng = make_rng(*rng_state, micro, site);
+  if (rng_state.has_value()) e.rng = make_rng(*rng_state, micro, site, sids, seq, sids.has_value() ? A.size(0) / seq : -1);
   if (layout == "nt") return gemm_nt(A, B, e, (int)tile);
   if (layout == "nn") return gemm_nn(A, B, e, (int)tile);
   TORCH_CHECK(false, "op_gemm: layout must be nt or nn");
@@ -543,38 +564,40 @@ std::vector<Tensor> op_layernorm_fwd(const Tensor& x, const Tensor& gamma, const
   return {y, stats};
 }
 std::vector<Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Tensor& gamma,
-                                     const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site) {
+                                     const c10::optional<Tensor>& rng_state, double drop_p, int64_t micro, int64_t site,
+                                     const OptTensor& sids, int64_t seq) {
   DeviceGuard guard(x.device());
   const int H = (int)x.size(1);
   auto f32 = stats.options();
   Tensor gg = at::zeros({H}, f32), gb = at::zeros({H}, f32), gbias = at::zeros({H}, f32);
   PdtRng rng{nullptr, 0, 0};
-  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site, sids, seq, sids.has_value() ? x.size(0) / seq : -1);
   LnBwdOut o = ln_bwd(dy.contiguous(), x, stats, gamma, &gg, &gb, &gbias, drop_p, rng, false);
   return {o.dx, o.ddrop, gg, gb, gbias};
 }
 std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, int64_t B, int64_t S, int64_t A,
-                                const c10::optional<Tensor>& rng_state, double p, int64_t micro, int64_t site) {
+                                const c10::optional<Tensor>& rng_state, double p, int64_t micro, int64_t site,
+                                const OptTensor& sids) {
   DeviceGuard guard(qkv.device());
   chk16(qkv, "qkv");
   TORCH_CHECK(qkv.is_contiguous() && qkv.size(0) == B * S && qkv.size(1) == 3 * A * 64, "qkv must be [B*S, 3*A*64]");
   Tensor ctx = at::empty({B * S, A * 64}, qkv.options());
   Tensor lse = at::empty({B, A, S}, qkv.options().dtype(at::kFloat));
   PdtRng rng{nullptr, 0, 0};
-  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site, sids, S, B);
   check(pdt_attn_fwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
                      lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p), thr16(p), rng, cur_stream()), "attn_fwd");
   return {ctx, lse};
 }
 Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, const Tensor& ctx, const Tensor& dctx,
                    const Tensor& lse, int64_t B, int64_t S, int64_t A, const c10::optional<Tensor>& rng_state, double p,
-                   int64_t micro, int64_t site, c10::optional<Tensor> dbias) {
+                   int64_t micro, int64_t site, c10::optional<Tensor> dbias, const OptTensor& sids) {
   DeviceGuard guard(qkv.device());
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
   Tensor dc = dctx.contiguous();
   PdtRng rng{nullptr, 0, 0};
-  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site);
+  if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site, sids, S, B);
   // `dbias` (fp32 [3H]): the column sums of dqkv are added to it (short-sequence kernel only)
   const int64_t H3 = qkv.size(1);
   Tensor part;
@@ -597,6 +620,7 @@ void bind_wordpiece(py::module_& m);  // wordpiece.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "gfx950 kernels + native runtime of pytorch_distributed_training_amd";
+  // (the trailing `sample_ids` arguments: optional int32 [B] global sample ids for sample-keyed dropout, see PdtRng)
   m.def("layer_forward", &layer_forward);
   m.def("layer_backward", &layer_backward);
   m.def("embed_forward", &embed_forward);
@@ -612,7 +636,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cast_to_16", &cast_to_16);
   m.def("op_gemm", &op_gemm, py::arg("layout"), py::arg("A"), py::arg("B"), py::arg("epi"), py::arg("bias"),
         py::arg("res"), py::arg("aux"), py::arg("rng_state"), py::arg("drop_p"), py::arg("micro"), py::arg("site"),
-        py::arg("tile"), py::arg("colsum") = py::none());
+        py::arg("tile"), py::arg("colsum") = py::none(), py::arg("sample_ids") = py::none(), py::arg("seq") = 1);
   m.def("op_gemm_tn", &op_gemm_tn);
   m.def("gemm_splits", [](const std::string& layout, const Tensor& A, const Tensor& B) {
     PdtGemm g{};
@@ -620,11 +644,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     return pdt_gemm_splits(layout == "nt" ? PDT_GEMM_NT : PDT_GEMM_NN, -1, &g);
   }, "K slices the dispatcher uses for a forward (nt) / dgrad (nn) GEMM of these operands (1 = one kernel)");
   m.def("op_layernorm_fwd", &op_layernorm_fwd);
-  m.def("op_layernorm_bwd", &op_layernorm_bwd);
-  m.def("op_attn_fwd", &op_attn_fwd);
+  m.def("op_layernorm_bwd", &op_layernorm_bwd, py::arg("dy"), py::arg("x"), py::arg("stats"), py::arg("gamma"),
+        py::arg("rng_state"), py::arg("drop_p"), py::arg("micro"), py::arg("site"), py::arg("sample_ids") = py::none(),
+        py::arg("seq") = 1);
+  m.def("op_attn_fwd", &op_attn_fwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("B"), py::arg("S"), py::arg("A"),
+        py::arg("rng_state"), py::arg("p"), py::arg("micro"), py::arg("site"), py::arg("sample_ids") = py::none());
   m.def("op_attn_bwd", &op_attn_bwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("ctx"), py::arg("dctx"),
         py::arg("lse"), py::arg("B"), py::arg("S"), py::arg("A"), py::arg("rng_state"), py::arg("p"), py::arg("micro"),
-        py::arg("site"), py::arg("dbias") = py::none());
+        py::arg("site"), py::arg("dbias") = py::none(), py::arg("sample_ids") = py::none());
   m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
         "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
   m.def("set_gemm_persistent", [](int64_t mode) { pdt_gemm_set_persist_mode((int)mode); },

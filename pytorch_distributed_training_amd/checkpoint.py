@@ -165,7 +165,7 @@ def save_training_state(directory: str, model: nn.Module, optimizer=None, schedu
         state["scheduler"] = scheduler.state_dict()
     rt = getattr(m, "runtime", None)
     if rt is not None:
-        state["rng"] = {"state": rt.rng_state.cpu(), "micro": rt.micro}
+        state["rng"] = {"state": rt.rng_state.cpu(), "micro": rt.micro, "window": rt.arena.window}
     state["torch_rng"] = torch.get_rng_state()
     path = os.path.join(sub, sname)
     tmp = path + ".tmp"
@@ -253,6 +253,7 @@ def load_training_state(directory: str, model: nn.Module, optimizer=None, schedu
     if rt is not None and "rng" in state:
         rt.rng_state.copy_(state["rng"]["state"].to(rt.rng_state.device))
         rt.micro = int(state["rng"]["micro"])
+        rt.arena.window = int(state["rng"].get("window", rt.arena.window))
     if "torch_rng" in state:
         torch.set_rng_state(state["torch_rng"])
     return state.get("extra", {})

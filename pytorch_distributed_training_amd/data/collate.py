@@ -51,4 +51,6 @@ class PadCollator:
         lab = "labels" if "labels" in examples[0] else ("label" if "label" in examples[0] else None)
         if lab is not None:
             out["labels"] = torch.as_tensor([e[lab] for e in examples], dtype=torch.long)
+        if "sample_ids" in examples[0]:  # global ids of the samples (data/loader.py adds them): sample-keyed dropout
+            out["sample_ids"] = torch.as_tensor([e["sample_ids"] for e in examples], dtype=torch.int32)
         return out

@@ -12,6 +12,7 @@ from typing import Iterator, Optional
 import torch
 from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler
 
+from .collate import PadCollator
 from .samplers import DistributedShardSampler, ShardedBatchSampler
 
 
@@ -33,6 +34,25 @@ class _EpochSeededRandomSampler(torch.utils.data.Sampler):
         return iter(torch.randperm(self.n, generator=g).tolist())
 
 
+class _WithSampleIds(torch.utils.data.Dataset):
+    """View of a dict-style dataset whose items also carry their dataset index as ``sample_ids``.  The native
+    kernels key dropout masks by it, which makes a mask a property of the sample and not of the rank / micro-batch
+    that happens to process it (ops.fused.NativeRuntime)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self) -> int:
+        return len(self.dataset)
+
+    def __getitem__(self, i):
+        item = self.dataset[i]
+        if isinstance(item, dict) and "sample_ids" not in item:
+            item = dict(item)
+            item["sample_ids"] = int(i)
+        return item
+
+
 def shard_dataloader(loader: DataLoader, num_processes: int, process_index: int, seed: int = 0,
                      even_batches: bool = True) -> DataLoader:
     """Re-build `loader` so that this rank iterates only its share of the batches."""
@@ -50,7 +70,10 @@ def shard_dataloader(loader: DataLoader, num_processes: int, process_index: int,
     else:
         inner = bs
     sharded = ShardedBatchSampler(inner, num_processes, process_index, even_batches)
-    return DataLoader(loader.dataset, batch_sampler=sharded, collate_fn=loader.collate_fn,
+    dataset = loader.dataset
+    if isinstance(loader.collate_fn, PadCollator) and not isinstance(dataset, _WithSampleIds):
+        dataset = _WithSampleIds(dataset)  # (only with the framework's own collator, which passes the ids through)
+    return DataLoader(dataset, batch_sampler=sharded, collate_fn=loader.collate_fn,
                       num_workers=loader.num_workers, pin_memory=loader.pin_memory,
                       persistent_workers=loader.persistent_workers if loader.num_workers > 0 else False)
 
@@ -83,7 +106,8 @@ class DeviceLoader:
 
     @property
     def dataset(self):
-        return self.loader.dataset
+        d = self.loader.dataset
+        return d.dataset if isinstance(d, _WithSampleIds) else d
 
     @property
     def batch_size(self):

@@ -60,8 +60,9 @@ class SyntheticPairDataset(Dataset):
         return self.examples[i]
 
 
-def fixed_batch(batch: int, seq_len: int, vocab_size: int, device, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """One device-resident full-length batch (benchmark input): no padding, both token types present."""
+def fixed_batch(batch: int, seq_len: int, vocab_size: int, device, seed: int = 0, first_id: int = 0) -> Dict[str, torch.Tensor]:
+    """One device-resident full-length batch (benchmark input): no padding, both token types present.  The
+    samples carry the global ids ``first_id ... first_id + batch - 1``."""
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(1000 if vocab_size > 2000 else 4, vocab_size, (batch, seq_len), generator=g)
     ids[:, 0] = min(CLS, vocab_size - 1)
@@ -75,4 +76,5 @@ def fixed_batch(batch: int, seq_len: int, vocab_size: int, device, seed: int = 0
         "token_type_ids": types.to(device),
         "attention_mask": torch.ones(batch, seq_len, dtype=torch.long, device=device),
         "labels": torch.randint(0, 2, (batch,), generator=g).to(device),
+        "sample_ids": torch.arange(first_id, first_id + batch, dtype=torch.int32).to(device),
     }

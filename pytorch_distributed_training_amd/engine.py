@@ -158,8 +158,9 @@ class Engine:
         if self.native:
             if not hasattr(model, "enable_native"):
                 raise TypeError("native 16-bit training needs a model with enable_native() (see models/bert.py)")
-            # distinct dropout streams per data-parallel rank, reproducible from (seed, rank)
-            model.enable_native(arena, seed=self.seed * 100003 + self.process_index)
+            # dropout streams: batches that carry global sample ids are keyed by (seed, step, sample) - the same masks
+            # whatever the parallel layout; other batches by (seed, rank, micro-batch): distinct per rank, reproducible
+            model.enable_native(arena, seed=self.seed * 100003 + self.process_index, global_seed=self.seed * 100003)
         if self.num_processes > 1:
             model = DataParallel(model, arena, self.pg, self.comm_dtype, comm_backend=self.comm_backend)
         self._models.append(model)

@@ -328,7 +328,7 @@ class _ClassifierBase(nn.Module):
 
         return bert_segments(self, prefix)
 
-    def enable_native(self, arena, seed: int = 0, prefix: str = "", runtime=None, site_offset: int = 0):
+    def enable_native(self, arena, seed: int = 0, prefix: str = "", runtime=None, site_offset: int = 0, global_seed=None):
         """Route embeddings / layers / pooler / head through the gfx950 kernels.  `arena` must hold this
         model's parameters with a 16-bit compute copy."""
         from ..ops import fused
@@ -338,7 +338,7 @@ class _ClassifierBase(nn.Module):
         cfg = self.config
         if cfg.head_dim != 64:
             raise ValueError("native attention kernels are specialised for head_dim == 64")
-        rt = runtime or fused.NativeRuntime(arena, seed)
+        rt = runtime or fused.NativeRuntime(arena, seed, global_seed)
         self.arena, self.runtime = arena, rt
         base = self.base_model
         bp = f"{prefix}{self.base_model_prefix}."
@@ -354,9 +354,11 @@ class _ClassifierBase(nn.Module):
             self._enable_native_head(arena, rt, prefix, arena.seg_index[f"{prefix}head"])
         return rt
 
-    def _begin_forward(self):
+    def _begin_forward(self, sample_ids=None):
+        """`sample_ids` ([B] global ids of the batch's samples, added by this framework's loaders): key the dropout
+        masks by sample instead of by rank-local row (ops.fused.NativeRuntime)."""
         if self.runtime is not None and self.training and torch.is_grad_enabled():
-            self.runtime.next_micro()
+            self.runtime.begin_forward(sample_ids)
 
     @property
     def base_model(self) -> BertModel:
@@ -433,8 +435,8 @@ class BertForSequenceClassification(_ClassifierBase):
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
-                **unused):
-        self._begin_forward()
+                sample_ids=None, **unused):
+        self._begin_forward(sample_ids)
         out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack
@@ -493,8 +495,8 @@ class RobertaForSequenceClassification(_ClassifierBase):
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
-                **unused):
-        self._begin_forward()
+                sample_ids=None, **unused):
+        self._begin_forward(sample_ids)
         out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack

@@ -57,10 +57,10 @@ class TriBert(nn.Module):
                 (heads if s.name.endswith("head") else segs).append(s)
         return segs + list(reversed(heads))  # tower 1's (the used) head completes first in backward
 
-    def enable_native(self, arena, seed: int = 0):
+    def enable_native(self, arena, seed: int = 0, global_seed=None):
         from ..ops import fused
 
-        rt = fused.NativeRuntime(arena, seed)
+        rt = fused.NativeRuntime(arena, seed, global_seed)
         for k, b in enumerate((self.bert_1, self.bert_2, self.bert_3), 1):
             b.enable_native(arena, prefix=f"bert_{k}.", runtime=rt, site_offset=1024 * k)
         self.arena, self.runtime = arena, rt
@@ -78,10 +78,11 @@ class TriBert(nn.Module):
         attention_mask = kwargs.pop("attention_mask")
         token_type_ids = kwargs.pop("token_type_ids")
         labels = kwargs.pop("labels", None)
+        sample_ids = kwargs.pop("sample_ids", None)
         if self.verbose:
             print("Input shape ", input_ids.size())
         if self.runtime is not None and self.training and torch.is_grad_enabled():
-            self.runtime.next_micro()
+            self.runtime.begin_forward(sample_ids)
         # the same embedding, pooler and classifier for the three towers
         word_embed = self.bert_1.get_input_embeddings()
         inputs_embeds = word_embed(input_ids)
@@ -111,6 +112,7 @@ class ConcatBert(nn.Module):
 
     def forward(self, *args, **kwargs):
         labels = kwargs.pop("labels", None)
+        kwargs.pop("sample_ids", None)
         input_shape = kwargs["input_ids"].size()
         hidden_states = self.bert_1.base_model(*args, **kwargs).last_hidden_state
         dev = self.second_device or hidden_states.device
@@ -152,10 +154,10 @@ class _TowerRank(nn.Module):
                 (heads if s.name.endswith("head") else segs).append(s)
         return segs + list(reversed(heads))
 
-    def enable_native(self, arena, seed: int = 0):
+    def enable_native(self, arena, seed: int = 0, global_seed=None):
         from ..ops import fused
 
-        rt = fused.NativeRuntime(arena, seed)
+        rt = fused.NativeRuntime(arena, seed, global_seed)
         for k in self.indices:
             getattr(self, f"bert_{k}").enable_native(arena, prefix=f"bert_{k}.", runtime=rt, site_offset=1024 * k)
         self.arena, self.runtime = arena, rt
@@ -179,7 +181,7 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
         dp.auto_arm = False
         dp.manual_finish = True
     if rt is not None and train:
-        rt.next_micro()
+        rt.begin_forward(batch.get("sample_ids"))
     dev = engine.device
     ids, mask, types = batch["input_ids"], batch["attention_mask"], batch["token_type_ids"]
     B, S = ids.shape

@@ -154,6 +154,7 @@ class ParamArena:
             for seg in self.segments:
                 seg.bucket = min(seg.bucket, len(self.bucket_bounds) - 2)
         self.written = [False] * len(self.segments)  # gradient slice holds this step's values already
+        self.window = 0  # accumulation windows started so far (= optimizer steps taken, on every rank alike)
         self.seg_index = {s.name: i for i, s in enumerate(self.segments)}
         self.param_segment: Dict[int, int] = {id(p): i for i, s in enumerate(self.segments) for _, p in s.params}
         if self.p16 is not None:
@@ -252,6 +253,7 @@ class ParamArena:
 
     def zero_grad(self) -> None:
         """Start a new accumulation window.  Slices whose producers overwrite on first touch are not memset."""
+        self.window += 1
         for i, seg in enumerate(self.segments):
             self.written[i] = False
             if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):

@@ -20,13 +20,39 @@ SITE_HEAD = 0x7F000010
 SITE_HEAD_PRE = 0x7F000011
 
 
-class NativeRuntime:
-    """Per-model state shared by the native nodes: RNG stream, micro-batch counter, completion hook."""
+class RngKey:
+    """What the dropout sites of one forward pass key their counters with (kept by every autograd node, so that
+    backward replays exactly its own forward's masks whatever ran in between)."""
 
-    def __init__(self, arena: ParamArena, seed: int = 0):
+    __slots__ = ("state", "counter", "sample_ids")
+
+    def __init__(self, state: torch.Tensor, counter: int, sample_ids: Optional[torch.Tensor]):
+        self.state, self.counter, self.sample_ids = state, counter, sample_ids
+
+    def rows(self, lo: int, hi: int) -> "RngKey":
+        return RngKey(self.state, self.counter, None if self.sample_ids is None else self.sample_ids[lo:hi].contiguous())
+
+
+class NativeRuntime:
+    """Per-model state shared by the native nodes: dropout streams, completion hook.
+
+    Two ways to key a dropout mask:
+
+    * a batch that carries ``sample_ids`` (the loaders of this framework add them): counters derive from (seed,
+      optimizer-step window, site, GLOBAL sample id, position, column).  A mask belongs to the sample, whichever
+      rank, pipeline micro-batch or padded length it is processed with, so data-parallel x model-parallel runs
+      reproduce the loss curve of a single GPU on the same global batch with dropout on.
+    * no ids: (rank-specific seed, per-rank micro-batch counter, site, local row, column) - distinct but
+      reproducible streams per rank, as a seeded torch generator per process would give.
+    """
+
+    def __init__(self, arena: ParamArena, seed: int = 0, global_seed: Optional[int] = None):
         self.arena = arena
         self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=arena.device)
-        self.micro = 0  # global micro-batch counter; part of every dropout counter
+        gs = seed if global_seed is None else global_seed
+        self.rng_state_global = torch.tensor([gs ^ 0x5BD1E995, 0], dtype=torch.int64, device=arena.device)
+        self.micro = 0  # per-rank micro-batch counter (the no-ids keying)
+        self.key = RngKey(self.rng_state, 0, None)  # of the forward pass in progress
         self.segment_done: Optional[Callable[[int], None]] = None  # set by the DP reducer wrapper
         # segments whose completion is reported later, by release(): a segment that gets part of its gradient outside
         # its native node (the word-embedding table of a tower-parallel rank, filled by a second backward call)
@@ -38,7 +64,18 @@ class NativeRuntime:
 
     def next_micro(self) -> int:
         self.micro = (self.micro + 1) & 0x7FFFFFFF
+        self.key = RngKey(self.rng_state, self.micro, None)
         return self.micro
+
+    def begin_forward(self, sample_ids: Optional[torch.Tensor] = None) -> RngKey:
+        """Start the forward pass of one (micro-)batch; returns the key its dropout sites use."""
+        if sample_ids is None:
+            self.next_micro()
+        else:
+            ids = sample_ids.reshape(-1).to(device=self.arena.device, dtype=torch.int32).contiguous()
+            # (the window counter advances with every zero_grad(), i.e. once per optimizer step on every rank)
+            self.key = RngKey(self.rng_state_global, self.arena.window & 0x7FFFFFFF, ids)
+        return self.key
 
     def done(self, seg: int) -> None:
         if seg in self.hold:
@@ -88,14 +125,14 @@ class _LayerFn(torch.autograd.Function):
         B, S, H = x.shape
         m, kvl = mask.native()
         train = layer.training
-        micro = nat.rt.micro
+        key = nat.rt.key
         x2 = x.reshape(B * S, H)
         outs = native().layer_forward(
-            x2, m, kvl, nat.w, nat.rt.rng_state, B, S, cfg.num_attention_heads,
+            x2, m, kvl, nat.w, key.state, B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            cfg.layer_norm_eps, micro, layer.index + nat.site_offset)
+            cfg.layer_norm_eps, key.counter, layer.index + nat.site_offset, key.sample_ids)
         ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl), x2, outs[1:]
-        ctx.meta = (B, S, H, train, micro)
+        ctx.meta = (B, S, H, train, key)
         return outs[0].view(B, S, H)
 
     @staticmethod
@@ -103,13 +140,13 @@ class _LayerFn(torch.autograd.Function):
         layer = ctx.layer
         nat: LayerNative = layer._native
         cfg = layer.cfg
-        B, S, H, train, micro = ctx.meta
+        B, S, H, train, key = ctx.meta
         acc = nat.arena.take_accumulate_flag(nat.segment)
         dx = native().layer_backward(
-            dy.reshape(B * S, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, nat.rt.rng_state,
+            dy.reshape(B * S, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, key.state,
             B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            micro, layer.index + nat.site_offset, acc)
+            key.counter, layer.index + nat.site_offset, acc, key.sample_ids)
         ctx.saved = ctx.x2 = None
         nat.rt.done(nat.segment)
         return dx.view(B, S, H), None, None
@@ -148,14 +185,15 @@ class _EmbedFn(torch.autograd.Function):
         cfg = emb.cfg
         B, S = pos_ids.shape
         train = emb.training
-        micro = nat.rt.micro
+        key = nat.rt.key
         idf = ids.reshape(-1).contiguous() if ids is not None else None
         ie = inputs_embeds.reshape(B * S, -1).contiguous() if inputs_embeds is not None else None
         pf, tf = pos_ids.reshape(-1).contiguous(), type_ids.reshape(-1).contiguous()
-        y, pre, stats = native().embed_forward(idf, pf, tf, ie, *nat.w, nat.rt.rng_state, cfg.layer_norm_eps,
-                                               cfg.hidden_dropout_prob if train else 0.0, micro, SITE_EMBED + nat.site_offset)
+        y, pre, stats = native().embed_forward(idf, pf, tf, ie, *nat.w, key.state, cfg.layer_norm_eps,
+                                               cfg.hidden_dropout_prob if train else 0.0, key.counter,
+                                               SITE_EMBED + nat.site_offset, key.sample_ids, S)
         ctx.emb, ctx.idx, ctx.saved = emb, (idf, pf, tf), (pre, stats)
-        ctx.meta = (B, S, train, micro, ie is not None)
+        ctx.meta = (B, S, train, key, ie is not None)
         return y.view(B, S, cfg.hidden_size)
 
     @staticmethod
@@ -163,13 +201,13 @@ class _EmbedFn(torch.autograd.Function):
         emb = ctx.emb
         nat: EmbedNative = emb._native
         cfg = emb.cfg
-        B, S, train, micro, has_ie = ctx.meta
+        B, S, train, key, has_ie = ctx.meta
         idf, pf, tf = ctx.idx
         pre, stats = ctx.saved
         acc = nat.arena.take_accumulate_flag(nat.segment)
         dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.g,
-                                       nat.rt.rng_state, cfg.hidden_dropout_prob if train else 0.0, micro,
-                                       SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc)
+                                       key.state, cfg.hidden_dropout_prob if train else 0.0, key.counter,
+                                       SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc, key.sample_ids, S)
         ctx.saved = None
         nat.rt.done(nat.segment)
         return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None)
@@ -234,22 +272,22 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pooled, nat, labels, p, site):
-        micro = nat.rt.micro
-        logits, loss = native().head_forward(pooled, nat.w, nat.b, labels, nat.rt.rng_state, p, micro, site)
+        key = nat.rt.key
+        logits, loss = native().head_forward(pooled, nat.w, nat.b, labels, key.state, p, key.counter, site, key.sample_ids)
         ctx.nat, ctx.has_labels = nat, labels is not None
         ctx.save_for_backward(pooled, logits, *([labels] if labels is not None else []))  # logits is an output
-        ctx.meta = (p, micro, site)
+        ctx.meta = (p, key, site)
         ctx.set_materialize_grads(False)  # an unused output arrives as None instead of a zero tensor
         return logits, loss
 
     @staticmethod
     def backward(ctx, dlogits, dloss):
         nat: HeadNative = ctx.nat
-        p, micro, site = ctx.meta
+        p, key, site = ctx.meta
         pooled, logits = ctx.saved_tensors[:2]
         labels = ctx.saved_tensors[2] if ctx.has_labels else None
         dp = native().head_backward(dloss if labels is not None else None, dlogits, pooled, nat.w, logits,
-                                    labels, nat.gw, nat.gb, nat.rt.rng_state, p, micro, site, True, False)
+                                    labels, nat.gw, nat.gb, key.state, p, key.counter, site, True, False, key.sample_ids)
         return dp, None, None, None, None
 
 
@@ -263,7 +301,7 @@ def classifier_head(pooled: torch.Tensor, nat: HeadNative, labels: Optional[torc
 
 
 def dropout16(x: torch.Tensor, rt: NativeRuntime, p: float, site: int) -> torch.Tensor:
-    """Counter-based dropout of a 16-bit tensor (same mask on forward and backward by construction)."""
+    """Counter-based dropout of a 16-bit [B, H] tensor (same mask on forward and backward by construction)."""
     if p <= 0.0:
         return x
     return _DropFn.apply(x, rt, p, site)
@@ -272,10 +310,11 @@ def dropout16(x: torch.Tensor, rt: NativeRuntime, p: float, site: int) -> torch.
 class _DropFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, rt, p, site):
-        ctx.rt, ctx.meta = rt, (p, rt.micro, site)
-        return native().dropout16(x, rt.rng_state, p, rt.micro, site)
+        key = rt.key
+        ctx.meta = (p, key, site)
+        return native().dropout16(x, key.state, p, key.counter, site, key.sample_ids)
 
     @staticmethod
     def backward(ctx, dy):
-        p, micro, site = ctx.meta
-        return native().dropout16(dy, ctx.rt.rng_state, p, micro, site), None, None, None
+        p, key, site = ctx.meta
+        return native().dropout16(dy, key.state, p, key.counter, site, key.sample_ids), None, None, None

@@ -167,7 +167,8 @@ class PipelineStage:
         for i in range(m):
             act.requires_grad_()
             c = chunks[i]
-            out = self.module(hidden_states=act, attention_mask=c["attention_mask"], labels=c["labels"])
+            out = self.module(hidden_states=act, attention_mask=c["attention_mask"], labels=c["labels"],
+                              sample_ids=c.get("sample_ids"))
             loss = out.loss * (c["labels"].shape[0] / total)  # exact batch-mean over unequal micro-batches
             if i == m - 1:
                 self._arm()
@@ -182,7 +183,7 @@ class PipelineStage:
 
     def _fwd_first(self, c: Dict[str, torch.Tensor]) -> torch.Tensor:
         out = self.module(input_ids=c["input_ids"], attention_mask=c["attention_mask"],
-                          token_type_ids=c.get("token_type_ids"))
+                          token_type_ids=c.get("token_type_ids"), sample_ids=c.get("sample_ids"))
         return out.last_hidden_state
 
     @torch.no_grad()

@@ -57,6 +57,7 @@ class GraphedStep:
         rt = getattr(self.engine.unwrap_model(self.model), "runtime", None)
         if rt is not None:
             rt.rng_state[1:2].add_(1)  # in-graph: every replay draws new dropout masks
+            rt.rng_state_global[1:2].add_(1)  # (the stream of batches that carry sample ids)
         n = len(self.static)
         loss = None
         for mb in self.static:

@@ -49,6 +49,25 @@ def test_tower_parallel_native_loss_curve(world):
         assert all(r["replicas_bit_equal"] is True for r in res)
 
 
+def test_dropout_masks_follow_the_sample_across_parallel_layouts():
+    """Dropout 0.1 ON (the reference trains with it in both scripts, /root/reference/test_model_parallelism.py:230-239):
+    masks are keyed by (seed, step, global sample id, position), so 2 data-parallel ranks, a 2-stage pipeline cut into
+    4 micro-batches, 2 replicas x 2 stages and the tower layout all reproduce the loss curve of ONE process on the same
+    global batch to fp16 tolerance - rank- or micro-batch-keyed masks differ by ~0.05 in the loss from step one."""
+    ref = W.gpu_single_reference("dp", steps=6, replicas=2, model="bert-tiny")
+    for got in run_distributed(W.gpu_dp_dropout, 2):
+        assert len(got) == 6 and max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+    for world, steps in ((2, 6), (4, 4)):
+        ref = W.gpu_single_reference("pipeline", steps=steps, replicas=world // 2, model="bert-tiny")
+        res = run_distributed(W.gpu_pipeline_recipe, world, args=("pipeline", False, "bert-tiny"))
+        got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
+        assert len(got) == steps and max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (world, got, ref)
+    ref = W.gpu_single_reference("towers", steps=4, replicas=2, model="bert-tiny")
+    res = run_distributed(W.gpu_pipeline_recipe, 4, args=("towers", False, "bert-tiny"))
+    got = [r for r in res if r["stage"] == 0 and r["replica"] == 0][0]["losses"][:4]
+    assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+
+
 def test_rccl_call_path_single_rank():
     """A 1-rank "nccl" (= RCCL) group with forced collectives: broadcast, bucketed all-reduce with the native
     AVG reduction on the communicator's stream, barrier - the API path the multi-GPU runs take."""

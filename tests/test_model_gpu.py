@@ -340,3 +340,50 @@ def test_segment_outside_the_graph_contributes_zero_gradient():
     assert arena.grad[seg.start:seg.end].abs().sum() == 0
     # the optimizer saw a zero gradient there: its first moment only decayed
     torch.testing.assert_close(opt.m[seg.start:seg.end], 0.9 * m_before, rtol=1e-6, atol=0)
+
+
+def test_sample_keyed_dropout_is_invariant_to_batch_split_and_padding():
+    """With sample ids the dropout masks (embeddings, attention probabilities, hidden states, head) belong to the
+    SAMPLE: a batch of 8, its two halves, and the same samples padded to a longer length give the same per-sample
+    logits with dropout 0.3 on - which is what lets data-/model-parallel runs reproduce a single-GPU run."""
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+
+    torch.manual_seed(0)
+    m = build_model("bert-tiny", hidden_dropout_prob=0.3, attention_probs_dropout_prob=0.3).cuda()
+    arena = ParamArena(m, torch.device("cuda"), torch.float16)
+    m.enable_native(arena, seed=7, global_seed=99)
+    g = torch.Generator().manual_seed(1)
+    B, S = 8, 40
+    ids = torch.randint(5, 512, (B, S), generator=g)
+    lens = torch.tensor([40, 33, 21, 40, 9, 17, 38, 25])
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    batch = {k: v.cuda() for k, v in dict(input_ids=ids * mask, attention_mask=mask, token_type_ids=torch.zeros_like(ids),
+                                           labels=torch.randint(0, 2, (B,), generator=g)).items()}
+    sids = torch.arange(100, 100 + B, dtype=torch.int32).cuda()
+    m.train()
+    full = m(**batch, sample_ids=sids).logits.clone()
+    again = m(**batch, sample_ids=sids).logits.clone()
+    assert torch.equal(full, again)                      # same window, same samples: same masks
+    halves = torch.cat([m(**{k: v[i:i + 4] for k, v in batch.items()}, sample_ids=sids[i:i + 4]).logits for i in (0, 4)])
+    torch.testing.assert_close(halves, full, rtol=2e-2, atol=2e-2)
+    # padded to 64 tokens instead of 40
+    pad = lambda t: torch.nn.functional.pad(t, (0, 24))
+    wide = {k: (pad(v) if v.dim() == 2 else v) for k, v in batch.items()}
+    torch.testing.assert_close(m(**wide, sample_ids=sids).logits, full, rtol=2e-2, atol=2e-2)
+    # other ids, or the next optimizer window: other masks
+    other = m(**batch, sample_ids=sids + 1000).logits
+    arena.zero_grad()
+    later = m(**batch, sample_ids=sids).logits
+    assert (other - full).abs().max() > 5e-2 and (later - full).abs().max() > 5e-2
+    # backward replays the masks of its own forward although another forward ran in between
+    arena.zero_grad()
+    out1 = m(**batch, sample_ids=sids)
+    _ = m(**{k: v[:4] for k, v in batch.items()}, sample_ids=sids[:4] + 7)
+    out1.loss.backward()
+    g1 = arena.grad.clone()
+    arena.window -= 1
+    arena.zero_grad()
+    m(**batch, sample_ids=sids).loss.backward()
+    rel = ((arena.grad - g1).norm() / g1.norm()).item()
+    assert rel < 1e-3, rel  # (embedding rows are accumulated with fp32 atomics: not bit-equal)
