@@ -110,10 +110,12 @@ int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_ids, const i
                   const void* inputs_embeds, const void* word, const void* pos, const void* type,
                   const void* gamma, const void* beta, void* pre, void* y, float* stats, int tokens, int H,
                   int V, int P, int R, float eps, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
-// scatter-add rows of d (16-bit [tokens,H]) into the fp32 tables gw[ids] (skipping `pad_id`) and
-// gp[pos_ids] with fp32 atomics; either table may be null; rows outside [0,V) / [0,P) are skipped
-int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw, float* gp,
-                      int tokens, int H, int V, int P, int64_t pad_id, void* stream);
+// table[idx[t]] += d[t] for the 16-bit rows d[0..n) (an embedding-table gradient), as a deterministic segmented sum:
+// `sorted` = the indices in ascending order (stable sort), `perm[i]` = the token of sorted position i, `scratch` =
+// fp32 [pdt_embed_seg_chunks(n)][2][H] work space.  Indices equal to skip_id or outside [0, rows) are ignored.
+int pdt_embed_seg_chunks(int n);
+int pdt_embed_scatter_sorted(int dtype, const void* d, const int64_t* sorted, const int64_t* perm, float* table,
+                             float* scratch, int n, int H, int rows, int64_t skip_id, void* stream);
 // token-type table gradient (R <= 4 rows) as deterministic masked column partial sums partial[nblk][R][H]
 // (finish with pdt_colsum_finish, nseg = R)
 int pdt_embed_type_partial(int dtype, const void* d, const int64_t* type_ids, float* partial, int* nblk, int tokens,

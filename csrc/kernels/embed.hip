@@ -76,25 +76,106 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// Word / position rows: fp32 atomic adds, 256 contiguous bytes per wave-instruction (one dword per lane).
-// The padding row of the word table receives no gradient (nn.Embedding padding_idx semantics).
+// Word / position table gradients: a deterministic segmented sum, no atomics.
+// The host sorts the row indices (stable), so equal indices form runs in the original token order; `perm` maps a
+// sorted position back to its token.  Stage 1 gives every ALIGNED chunk of SEG_CH sorted positions to one wave (per
+// block of 512 columns): it walks the chunk in order, sums the rows of each run and, at the end of a run, either adds
+// the sum to the table row (the run lies inside the chunk: this wave is the row's only writer) or parks it in
+// scratch[chunk][slot] (the run crosses a chunk border: slot 0 when it comes in from the previous chunk, else slot 1
+// when it goes on into the next one).  Stage 2 finishes the runs that span chunks: the wave of the chunk where such a
+// run STARTS adds up its parked sums in chunk order and writes the row.  A hot row ([CLS], [SEP], every position
+// row: >= 1024 summands at the benchmark batch) is thereby summed by many waves in parallel, yet always in the same
+// order, so the gradient is bit-reproducible.  Indices equal to `skip_id` (nn.Embedding's padding_idx) or outside
+// the table contribute nothing.
+constexpr int SEG_CH = 32;
+
 template <typename T>
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const T* __restrict__ d, const int64_t* __restrict__ ids,
-                                                            const int64_t* __restrict__ pos_ids, float* __restrict__ gw,
-                                                            float* __restrict__ gp, int tokens, int H, int V, int P,
-                                                            int64_t pad_id) {
+__global__ __launch_bounds__(256) void embed_seg_stage1_kernel(const T* __restrict__ d, const int64_t* __restrict__ sorted,
+                                                               const int64_t* __restrict__ perm, float* __restrict__ table,
+                                                               float* __restrict__ scratch, int n, int H, int rows,
+                                                               int64_t skip_id) {
   const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= tokens) return;
-  const int64_t id = ids ? ids[tok] : -1;
-  float* wrow = (gw && ids && id != pad_id && id >= 0 && id < V) ? gw + (size_t)id * H : nullptr;
-  const int64_t ps = gp ? pos_ids[tok] : -1;
-  float* prow = (gp && ps >= 0 && ps < P) ? gp + (size_t)ps * H : nullptr;
-  for (int c = lane; c < H; c += 64) {
-    const float v = Half16<T>::to_f(reinterpret_cast<const short*>(d)[(size_t)tok * H + c]);
-    if (wrow) atomicAdd(wrow + c, v);
-    if (prow) atomicAdd(prow + c, v);
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p0 = chunk * SEG_CH;
+  if (p0 >= n) return;
+  const int col = blockIdx.y * 512 + lane * 8;
+  if (col >= H) return;
+  const int p1 = min(n, p0 + SEG_CH);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int64_t cur = sorted[p0];
+  int first = p0;
+  auto flush = [&](int last) {  // the run of `cur` occupies sorted positions [first, last] of this chunk
+    if (cur != skip_id && cur >= 0 && cur < rows) {
+      const bool head_open = first == p0 && p0 > 0 && sorted[p0 - 1] == cur;
+      const bool tail_open = last == p1 - 1 && p1 < n && sorted[p1] == cur;
+      float* dst = (head_open || tail_open) ? scratch + ((size_t)chunk * 2 + (head_open ? 0 : 1)) * H + col
+                                            : table + (size_t)cur * H + col;
+      float4v a = {acc[0], acc[1], acc[2], acc[3]}, b = {acc[4], acc[5], acc[6], acc[7]};
+      if (!(head_open || tail_open)) {
+        a += *reinterpret_cast<const float4v*>(dst);
+        b += *reinterpret_cast<const float4v*>(dst + 4);
+      }
+      *reinterpret_cast<float4v*>(dst) = a;
+      *reinterpret_cast<float4v*>(dst + 4) = b;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  };
+  for (int p = p0; p < p1; p += 8) {
+    short8 v[8];
+    int64_t id[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // 8 independent row loads in flight
+      const int q = min(p + u, p1 - 1);
+      id[u] = sorted[q];
+      v[u] = *reinterpret_cast<const short8*>(d + (size_t)perm[q] * H + col);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (p + u >= p1) break;
+      if (id[u] != cur) {
+        flush(p + u - 1);
+        cur = id[u];
+        first = p + u;
+      }
+      float f[8];
+      unpack8<T>(v[u], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
   }
+  flush(p1 - 1);
+}
+
+__global__ __launch_bounds__(256) void embed_seg_stage2_kernel(const int64_t* __restrict__ sorted, float* __restrict__ table,
+                                                               const float* __restrict__ scratch, int n, int H, int rows,
+                                                               int64_t skip_id) {
+  const int lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p0 = chunk * SEG_CH;
+  if (p0 >= n) return;
+  const int col = blockIdx.y * 512 + lane * 8;
+  if (col >= H) return;
+  const int p1 = min(n, p0 + SEG_CH);
+  const int64_t id = sorted[p1 - 1];
+  if (!(p1 < n && sorted[p1] == id)) return;                       // the last run of this chunk ends here
+  if (sorted[p0] == id && p0 > 0 && sorted[p0 - 1] == id) return;   // ... or started in an earlier chunk
+  if (id == skip_id || id < 0 || id >= rows) return;
+  // this chunk holds the start of a run that goes on: its own tail sum, then the head sums of the chunks it crosses
+  const float* src = scratch + ((size_t)chunk * 2 + 1) * H + col;
+  float4v a = *reinterpret_cast<const float4v*>(src), b = *reinterpret_cast<const float4v*>(src + 4);
+  for (int c = chunk + 1; c * SEG_CH < n; ++c) {
+    src = scratch + (size_t)c * 2 * H + col;
+    a += *reinterpret_cast<const float4v*>(src);
+    b += *reinterpret_cast<const float4v*>(src + 4);
+    const int e = min(n, (c + 1) * SEG_CH);
+    if (!(sorted[e - 1] == id && e < n && sorted[e] == id)) break;  // the run ends inside chunk c
+  }
+  float* dst = table + (size_t)id * H + col;
+  a += *reinterpret_cast<const float4v*>(dst);
+  b += *reinterpret_cast<const float4v*>(dst + 4);
+  *reinterpret_cast<float4v*>(dst) = a;
+  *reinterpret_cast<float4v*>(dst + 4) = b;
 }
 
 // Token-type table (<= 4 rows): masked column sums, deterministic.  partial[nblk][R][H]
@@ -147,16 +228,21 @@ extern "C" int pdt_embed_fwd(int dtype, const int64_t* ids, const int64_t* pos_i
   return (int)hipGetLastError();
 }
 
-extern "C" int pdt_embed_scatter(int dtype, const void* d, const int64_t* ids, const int64_t* pos_ids, float* gw,
-                                 float* gp, int tokens, int H, int V, int P, int64_t pad_id, void* stream) {
-  if (tokens <= 0 || (gw && V <= 0) || (gp && P <= 0)) return -3;
-  const dim3 grid((tokens + 3) / 4), block(256);
+extern "C" int pdt_embed_seg_chunks(int n) { return (n + SEG_CH - 1) / SEG_CH; }
+
+extern "C" int pdt_embed_scatter_sorted(int dtype, const void* d, const int64_t* sorted, const int64_t* perm, float* table,
+                                        float* scratch, int n, int H, int rows, int64_t skip_id, void* stream) {
+  if (n <= 0 || rows <= 0 || (H & 7) || !table || !scratch) return -3;
+  const int chunks = pdt_embed_seg_chunks(n);
+  const dim3 grid((chunks + 3) / 4, (H + 511) / 512), block(256);
   if (dtype == PDT_F16)
-    hipLaunchKernelGGL(embed_scatter_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16*)d, ids,
-                       pos_ids, gw, gp, tokens, H, V, P, pad_id);
+    hipLaunchKernelGGL(embed_seg_stage1_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, (const _Float16*)d, sorted,
+                       perm, table, scratch, n, H, rows, skip_id);
   else
-    hipLaunchKernelGGL(embed_scatter_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)d, ids,
-                       pos_ids, gw, gp, tokens, H, V, P, pad_id);
+    hipLaunchKernelGGL(embed_seg_stage1_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, (const __bf16*)d, sorted, perm,
+                       table, scratch, n, H, rows, skip_id);
+  hipLaunchKernelGGL(embed_seg_stage2_kernel, grid, block, 0, (hipStream_t)stream, sorted, table, (const float*)scratch, n, H,
+                     rows, skip_id);
   return (int)hipGetLastError();
 }
 

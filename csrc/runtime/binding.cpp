@@ -411,10 +411,19 @@ Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stat
     gr[0].zero_();
     gr[1].zero_();
   }
-  check(pdt_embed_scatter(dt_code(pre), l.dx.data_ptr(), ids.has_value() ? ids->data_ptr<int64_t>() : nullptr,
-                          pos_ids.data_ptr<int64_t>(), ids.has_value() ? gr[0].data_ptr<float>() : nullptr,
-                          gr[1].data_ptr<float>(), tokens, H, (int)gr[0].size(0), (int)gr[1].size(0), pad_id, cur_stream()),
-        "embed_scatter");
+  // word / position tables: sort the indices once (stable: equal indices keep their token order), then the
+  // segmented-sum kernels add every run of equal indices to its row - deterministic, no atomics
+  auto scatter = [&](const Tensor& idx, Tensor& table, int64_t skip) {
+    auto sorted_perm = at::sort(idx, /*stable=*/true, /*dim=*/0, /*descending=*/false);
+    const Tensor& sorted = std::get<0>(sorted_perm);
+    const Tensor& perm = std::get<1>(sorted_perm);
+    Tensor scratch = at::empty({(int64_t)pdt_embed_seg_chunks(tokens) * 2 * H}, stats.options());
+    check(pdt_embed_scatter_sorted(dt_code(pre), l.dx.data_ptr(), sorted.data_ptr<int64_t>(), perm.data_ptr<int64_t>(),
+                                   table.data_ptr<float>(), scratch.data_ptr<float>(), tokens, H, (int)table.size(0), skip,
+                                   cur_stream()), "embed_scatter_sorted");
+  };
+  if (ids.has_value()) scatter(*ids, gr[0], pad_id);
+  scatter(pos_ids, gr[1], -1);
   const int R = (int)gr[2].size(0);
   Tensor partial = at::empty({256, R, H}, stats.options());
   int nblk = 0;

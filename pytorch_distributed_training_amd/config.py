@@ -49,6 +49,7 @@ class TrainConfig:
     vocab_file: Optional[str] = None
     train_examples: int = 3668
     eval_examples: int = 408
+    data_vocab: Optional[int] = None  # synthetic data: draw word tokens from this many ids only (None: whole vocabulary)
     max_length: Optional[int] = None  # None: pad to the longest sample of each batch
     pad_to_multiple_of: Optional[int] = None
     # behaviour switches

@@ -22,12 +22,16 @@ CLS, SEP, PAD = 101, 102, 0
 class SyntheticPairDataset(Dataset):
     def __init__(self, num_examples: int = MRPC_TRAIN, vocab_size: int = 28996, seq_len: Optional[int] = None,
                  min_len: int = 8, max_len: int = 64, seed: int = 0, copy_noise: float = 0.15,
-                 special_floor: int = 1000, roberta: bool = False):
+                 special_floor: int = 1000, roberta: bool = False, data_vocab: Optional[int] = None):
         """``seq_len``: if given every example has exactly this many tokens (fixed-shape benchmark data),
-        otherwise sentence lengths are ragged in ``[min_len, max_len]`` per sentence."""
+        otherwise sentence lengths are ragged in ``[min_len, max_len]`` per sentence.  ``data_vocab``: draw the
+        word tokens from only this many ids (a small working vocabulary makes the rule learnable from random
+        initialisation within a few thousand steps; natural text concentrates on few ids in the same way)."""
         rng = np.random.default_rng(seed)
         self.examples: List[Dict[str, List[int]]] = []
         lo = min(special_floor, vocab_size // 4)
+        if data_vocab:
+            vocab_size = min(vocab_size, lo + int(data_vocab))
         cls, sep = (0, 2) if roberta else (CLS, SEP)
         cls, sep = min(cls, vocab_size - 1), min(sep, vocab_size - 1)
         self.roberta = roberta

@@ -357,8 +357,8 @@ class _ClassifierBase(nn.Module):
     def _begin_forward(self, sample_ids=None):
         """`sample_ids` ([B] global ids of the batch's samples, added by this framework's loaders): key the dropout
         masks by sample instead of by rank-local row (ops.fused.NativeRuntime)."""
-        if self.runtime is not None and self.training and torch.is_grad_enabled():
-            self.runtime.begin_forward(sample_ids)
+        if self.runtime is not None:
+            self.runtime.begin_forward(sample_ids, train=self.training and torch.is_grad_enabled())
 
     @property
     def base_model(self) -> BertModel:

@@ -81,8 +81,8 @@ class TriBert(nn.Module):
         sample_ids = kwargs.pop("sample_ids", None)
         if self.verbose:
             print("Input shape ", input_ids.size())
-        if self.runtime is not None and self.training and torch.is_grad_enabled():
-            self.runtime.begin_forward(sample_ids)
+        if self.runtime is not None:
+            self.runtime.begin_forward(sample_ids, train=self.training and torch.is_grad_enabled())
         # the same embedding, pooler and classifier for the three towers
         word_embed = self.bert_1.get_input_embeddings()
         inputs_embeds = word_embed(input_ids)
@@ -180,8 +180,8 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
         # so it is closed explicitly after the second one instead of by autograd's end-of-backward callback
         dp.auto_arm = False
         dp.manual_finish = True
-    if rt is not None and train:
-        rt.begin_forward(batch.get("sample_ids"))
+    if rt is not None:
+        rt.begin_forward(batch.get("sample_ids"), train=train)
     dev = engine.device
     ids, mask, types = batch["input_ids"], batch["attention_mask"], batch["token_type_ids"]
     B, S = ids.shape

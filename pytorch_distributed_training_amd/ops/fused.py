@@ -67,9 +67,12 @@ class NativeRuntime:
         self.key = RngKey(self.rng_state, self.micro, None)
         return self.micro
 
-    def begin_forward(self, sample_ids: Optional[torch.Tensor] = None) -> RngKey:
-        """Start the forward pass of one (micro-)batch; returns the key its dropout sites use."""
-        if sample_ids is None:
+    def begin_forward(self, sample_ids: Optional[torch.Tensor] = None, train: bool = True) -> RngKey:
+        """Start the forward pass of one (micro-)batch; returns the key its dropout sites use.  An evaluation pass
+        (``train=False``: dropout off) consumes nothing and carries no ids."""
+        if not train:
+            self.key = RngKey(self.rng_state, self.micro, None)
+        elif sample_ids is None:
             self.next_micro()
         else:
             ids = sample_ids.reshape(-1).to(device=self.arena.device, dtype=torch.int32).contiguous()

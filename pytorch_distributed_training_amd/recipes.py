@@ -57,8 +57,10 @@ def build_datasets(cfg: TrainConfig, model_cfg):
     room = model_cfg.max_position_embeddings - (model_cfg.pad_token_id + 1 if roberta else 0)
     limit = min(room, cfg.max_length) if cfg.max_length else room
     max_len = max(4, min(64, (limit - 3) // 2))
-    train = SyntheticPairDataset(cfg.train_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed, roberta=roberta)
-    val = SyntheticPairDataset(cfg.eval_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed + 1, roberta=roberta)
+    train = SyntheticPairDataset(cfg.train_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed, roberta=roberta,
+                                 data_vocab=cfg.data_vocab)
+    val = SyntheticPairDataset(cfg.eval_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed + 1, roberta=roberta,
+                               data_vocab=cfg.data_vocab)
     return train, val
 
 

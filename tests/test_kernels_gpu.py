@@ -102,7 +102,7 @@ def test_gemm_dropout_epilogue_statistics_and_replay(dtype):
     assert not torch.equal(z1, z3)
     # the standalone dropout kernel regenerates the same mask (what LN backward relies on)
     ones = torch.ones(M, N, device="cuda", dtype=dtype)
-    d = C().dropout16(ones, st, 0.1, 2, 5)
+    d = C().dropout16(ones, st, 0.1, 2, 5, None)
     assert torch.equal(d != 0, z1 != 0)
 
 
@@ -183,7 +183,7 @@ def test_layernorm_fwd_bwd(dtype, rows, H):
     # with dropout: ddrop = mask * dx / keep, and the bias gradient sums ddrop
     st = rng_state(5, 1)
     dx2, ddrop2, _, _, gbias2 = C().op_layernorm_bwd(dy, x, stats, g, st, 0.25, 1, 9)
-    mask = C().dropout16(torch.ones_like(x), st, 0.25, 1, 9)
+    mask = C().dropout16(torch.ones_like(x), st, 0.25, 1, 9, None)
     assert torch.equal(dx2, dx)
     torch.testing.assert_close(ddrop2.float(), dx.float() * mask.float(), rtol=1e-2, atol=1e-3)
     assert rel_err(gbias2, ddrop2.float().sum(0)) < 1e-3
@@ -356,7 +356,7 @@ def test_embeddings_fwd_bwd(dtype):
     pids = torch.arange(S, device="cuda").repeat(B)
     tids = torch.randint(0, R, (B * S,), device="cuda")
     st = rng_state()
-    y, pre, stats = C().embed_forward(ids, pids, tids, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+    y, pre, stats = C().embed_forward(ids, pids, tids, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
     wf, pf, tf = word.float().requires_grad_(), pos.float().requires_grad_(), typ.float().requires_grad_()
     gf, bf = g.float().requires_grad_(), b.float().requires_grad_()
     e = F.embedding(ids, wf, padding_idx=0) + F.embedding(pids, pf) + F.embedding(tids, tf)
@@ -367,10 +367,51 @@ def test_embeddings_fwd_bwd(dtype):
     f32 = dict(device="cuda", dtype=torch.float32)
     grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
              torch.zeros(H, **f32)]
-    C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, False)
+    C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, False, None, 1)
     for got, want in zip(grads, [wf.grad, pf.grad, tf.grad, gf.grad, bf.grad]):
         assert rel_err(got, want) < 2e-2
     assert grads[0][0].abs().max().item() == 0  # padding row
+
+
+def test_embedding_table_gradients_are_a_deterministic_segmented_sum():
+    """Hot rows ([CLS] / [SEP] once per sample, every position row B times) span many 32-row chunks of the sorted
+    index list, cold rows lie inside one; the result equals an fp32 index_add, two runs are bit-identical, and a
+    second call accumulates on top of the first."""
+    torch.manual_seed(3)
+    dtype = torch.float16
+    V, P, R, H, B, S = 1000, 128, 2, 1024, 96, 128
+    T = B * S
+    ids = torch.randint(3, V, (B, S), device="cuda")
+    ids[:, 0] = 1          # a row with B summands
+    ids[:, 5:70:3] = 2     # a row with B * 22 summands
+    ids[3, 100:] = 0       # padding_idx
+    ids[7, 11] = V + 9     # outside the table: skipped
+    ids = ids.reshape(-1)
+    pids = torch.arange(S, device="cuda").repeat(B)
+    tids = torch.zeros(T, dtype=torch.long, device="cuda")
+    g = torch.ones(H, device="cuda", dtype=dtype)
+    pre = torch.randn(T, H, device="cuda").to(dtype)
+    stats = torch.stack([pre.float().mean(1), torch.rsqrt(pre.float().var(1, unbiased=False) + 1e-12)], 1).contiguous()
+    dy = torch.randn(T, H, device="cuda").to(dtype)
+    st = rng_state()
+    f32 = dict(device="cuda", dtype=torch.float32)
+
+    def run(grads, acc):
+        return C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, acc, None, 1)
+
+    mk = lambda: [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
+                  torch.zeros(H, **f32)]
+    g1, g2 = mk(), mk()
+    dx = run(g1, False).float()
+    run(g2, False)
+    assert torch.equal(g1[0], g2[0]) and torch.equal(g1[1], g2[1])
+    valid = (ids != 0) & (ids < V)
+    want_w = torch.zeros(V, H, **f32).index_add_(0, ids[valid], dx[valid])
+    want_p = torch.zeros(P, H, **f32).index_add_(0, pids, dx)
+    assert rel_err(g1[0], want_w) < 1e-5 and rel_err(g1[1], want_p) < 1e-5
+    assert g1[0][0].abs().max().item() == 0
+    run(g1, True)  # accumulate: twice the gradient
+    assert rel_err(g1[0], 2 * want_w) < 1e-5 and rel_err(g1[1], 2 * want_p) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -382,7 +423,7 @@ def test_head_fwd_bwd(dtype):
     bias = torch.randn(Cn, device="cuda") * 0.1
     labels = torch.randint(0, Cn, (B,), device="cuda")
     st = rng_state()
-    logits, loss = C().head_forward(pooled, W, bias, labels, st, 0.0, 0, 0)
+    logits, loss = C().head_forward(pooled, W, bias, labels, st, 0.0, 0, 0, None)
     pf = pooled.float().requires_grad_()
     Wf, bf = W.clone().requires_grad_(), bias.clone().requires_grad_()
     rl = F.linear(pf, Wf, bf)
@@ -391,7 +432,7 @@ def test_head_fwd_bwd(dtype):
     torch.testing.assert_close(loss, rloss, rtol=1e-5, atol=1e-5)
     (rloss * 3.0).backward()
     gW, gb = torch.zeros_like(W), torch.zeros_like(bias)
-    dp = C().head_backward(torch.tensor(3.0, device="cuda"), None, pooled, W, logits, labels, gW, gb, st, 0.0, 0, 0, False, False)
+    dp = C().head_backward(torch.tensor(3.0, device="cuda"), None, pooled, W, logits, labels, gW, gb, st, 0.0, 0, 0, False, False, None)
     assert rel_err(dp, pf.grad) < 1e-2
     assert rel_err(gW, Wf.grad) < 1e-4
     assert rel_err(gb, bf.grad) < 1e-4
@@ -609,15 +650,15 @@ def test_embedding_indices_outside_their_tables_are_clamped_not_dereferenced():
     bad_ids, bad_p, bad_t = ids.clone(), pids.clone(), tids.clone()
     bad_ids[3], bad_ids[10], bad_p[5], bad_t[7], bad_t[8] = V + 5, -4, P + 100, 28995, -1
     st = rng_state()
-    y_bad, pre_bad, stats_bad = C().embed_forward(bad_ids, bad_p, bad_t, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+    y_bad, pre_bad, stats_bad = C().embed_forward(bad_ids, bad_p, bad_t, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
     y_ref, _, _ = C().embed_forward(bad_ids.clamp(0, V - 1), bad_p.clamp(0, P - 1), bad_t.clamp(0, R - 1), None, word,
-                                    pos, typ, g, b, st, 1e-12, 0.0, 0, 0)
+                                    pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
     assert torch.equal(y_bad, y_ref)
     f32 = dict(device="cuda", dtype=torch.float32)
     grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
              torch.zeros(H, **f32)]
     dy = torch.randn(T, H, device="cuda").to(dtype)
-    C().embed_backward(dy, pre_bad, stats_bad, bad_ids, bad_p, bad_t, g, grads, st, 0.0, 0, 0, 0, False)
+    C().embed_backward(dy, pre_bad, stats_bad, bad_ids, bad_p, bad_t, g, grads, st, 0.0, 0, 0, 0, False, None, 1)
     torch.cuda.synchronize()
     assert all(torch.isfinite(x).all() for x in grads)
     # rows of valid tokens received their gradient; nothing was written for the out-of-table word / position rows
