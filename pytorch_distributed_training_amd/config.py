@@ -49,6 +49,8 @@ class TrainConfig:
     vocab_file: Optional[str] = None
     train_examples: int = 3668
     eval_examples: int = 408
+    data_rule: str = "copy"  # synthetic data: what makes a pair label 1 ("copy" | "topic", see data/synthetic.py)
+    data_topics: int = 8     # synthetic data, rule "topic": number of vocabulary slices
     data_vocab: Optional[int] = None  # synthetic data: draw word tokens from this many ids only (None: whole vocabulary)
     max_length: Optional[int] = None  # None: pad to the longest sample of each batch
     pad_to_multiple_of: Optional[int] = None

@@ -22,11 +22,17 @@ CLS, SEP, PAD = 101, 102, 0
 class SyntheticPairDataset(Dataset):
     def __init__(self, num_examples: int = MRPC_TRAIN, vocab_size: int = 28996, seq_len: Optional[int] = None,
                  min_len: int = 8, max_len: int = 64, seed: int = 0, copy_noise: float = 0.15,
-                 special_floor: int = 1000, roberta: bool = False, data_vocab: Optional[int] = None):
+                 special_floor: int = 1000, roberta: bool = False, data_vocab: Optional[int] = None,
+                 rule: str = "copy", topics: int = 8):
         """``seq_len``: if given every example has exactly this many tokens (fixed-shape benchmark data),
         otherwise sentence lengths are ragged in ``[min_len, max_len]`` per sentence.  ``data_vocab``: draw the
-        word tokens from only this many ids (a small working vocabulary makes the rule learnable from random
-        initialisation within a few thousand steps; natural text concentrates on few ids in the same way)."""
+        word tokens from only this many ids.  ``rule``: what makes a pair a "paraphrase" (label 1) -
+        ``"copy"``: sentence 2 is a noisy copy of sentence 1 (needs token-by-token comparison across the separator);
+        ``"topic"``: both sentences draw their words from the same one of ``topics`` disjoint slices of the vocabulary,
+        label 0 pairs from two different slices (a sentence-pair relation a randomly initialised encoder picks up
+        within a few hundred steps - the convergence tests and logs use it)."""
+        if rule not in ("copy", "topic", "marker"):
+            raise ValueError("rule must be 'copy', 'topic' or 'marker'")
         rng = np.random.default_rng(seed)
         self.examples: List[Dict[str, List[int]]] = []
         lo = min(special_floor, vocab_size // 4)
@@ -44,8 +50,21 @@ class SyntheticPairDataset(Dataset):
                 l1 = int(rng.integers(min_len, max_len + 1))
                 l2 = int(rng.integers(min_len, max_len + 1))
             label = int(rng.integers(0, 2))
-            s1 = rng.integers(lo, vocab_size, size=l1)
-            if label == 1:
+            if rule == "marker":  # (a bag-of-words sanity rule: sentence 2 from the upper / lower half of the vocabulary)
+                mid = (lo + vocab_size) // 2
+                s1 = rng.integers(lo, vocab_size, size=l1)
+                s2 = rng.integers(mid, vocab_size, size=l2) if label == 1 else rng.integers(lo, mid, size=l2)
+            elif rule == "topic":
+                width = max(1, (vocab_size - lo) // topics)
+                t1 = int(rng.integers(0, topics))
+                t2 = t1 if label == 1 else int((t1 + rng.integers(1, topics)) % topics)
+                s1 = rng.integers(lo + t1 * width, lo + (t1 + 1) * width, size=l1)
+                s2 = rng.integers(lo + t2 * width, lo + (t2 + 1) * width, size=l2)
+            else:
+                s1 = rng.integers(lo, vocab_size, size=l1)
+            if rule in ("topic", "marker"):
+                pass
+            elif label == 1:
                 base = np.resize(s1, l2)
                 noise = rng.random(l2) < copy_noise
                 s2 = np.where(noise, rng.integers(lo, vocab_size, size=l2), base)

@@ -58,9 +58,9 @@ def build_datasets(cfg: TrainConfig, model_cfg):
     limit = min(room, cfg.max_length) if cfg.max_length else room
     max_len = max(4, min(64, (limit - 3) // 2))
     train = SyntheticPairDataset(cfg.train_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed, roberta=roberta,
-                                 data_vocab=cfg.data_vocab)
+                                 data_vocab=cfg.data_vocab, rule=cfg.data_rule, topics=cfg.data_topics)
     val = SyntheticPairDataset(cfg.eval_examples, model_cfg.vocab_size, max_len=max_len, seed=cfg.seed + 1, roberta=roberta,
-                               data_vocab=cfg.data_vocab)
+                               data_vocab=cfg.data_vocab, rule=cfg.data_rule, topics=cfg.data_topics)
     return train, val
 
 
