@@ -116,15 +116,15 @@ def main() -> None:
                         first_id=eng.process_index * args.batch + (i % args.accum) * micro) for i in range(4)]
 
     def step(i: int) -> torch.Tensor:
-        loss = None
-        for a in range(args.accum):
-            batch = pool[(i * args.accum + a) % len(pool)]
-            last = a == args.accum - 1
-            ctx = eng.no_sync(model) if not last else _null()
-            with ctx:
-                out = model(**batch)
-                loss = out.loss / args.accum
-                eng.backward(loss)
+        if args.accum > 1:
+            # one accumulation window: micro-batch i+1's forward is enqueued next to micro-batch i's backward
+            # (Engine.accumulate; PDT_OVERLAP_MICRO=0 gives the plain loop), one gradient reduction at its end
+            losses = eng.accumulate(model, [pool[(i * args.accum + a) % len(pool)] for a in range(args.accum)])
+            loss = losses[-1] / args.accum
+        else:
+            out = model(**pool[i % len(pool)])
+            loss = out.loss
+            eng.backward(loss)
         optimizer.step()
         sched.step()
         optimizer.zero_grad()

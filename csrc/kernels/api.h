@@ -62,10 +62,14 @@ typedef struct PdtGemm {
   int ws_splits;
   // (set by the launcher) per-XCD ticket counters of a persistent launch of the 256x256 ping-pong kernel
   uint32_t* sync;
+  // EPI_SLAB_F32 with ONE slab: add the tile to what C holds instead of overwriting it - a weight gradient whose K
+  // is not split accumulates straight into the gradient arena, with no slab buffer and no reduction kernel
+  int slab_accumulate;
 } PdtGemm;
 
-// tile: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves, one barrier per K-tile), 2 = 256x256 ping-pong
-// (8 waves in two staggered groups, counted LDS-DMA waits), -1 = choose from the shape.
+// tile: 0 = 128x128 (4 waves, double-buffered, 2 workgroups per CU), 1 = 256x256 (8 waves, one barrier per K-tile),
+// 2 = 256x256 ping-pong (8 waves in two staggered groups, counted LDS-DMA waits), 3 = 128x128 with a 4-deep K-tile
+// ring (1 workgroup per CU; for launches of about one workgroup per CU or fewer), -1 = choose from the shape.
 // For TN, C is the fp32 slab buffer [splits][M][ldc] and g->splits / k_per_split select the K split
 // (0 = choose); the chosen values are written back into *g.
 int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);
@@ -79,6 +83,9 @@ int pdt_gemm_max_splits(void);
 // granularity instead of at the end of a whole GEMM).
 int pdt_gemm_persist_mode(void);
 void pdt_gemm_set_persist_mode(int mode);
+// K split of forward / dgrad GEMMs with few output tiles (see pdt_gemm_splits): 1 on (default), 0 off
+void pdt_gemm_set_split_mode(int on);
+int pdt_gemm_split_mode(void);
 // slabs a TN (weight-gradient) GEMM of this shape writes (g->splits > 0: that many); size C accordingly
 int pdt_gemm_tn_splits(int tile, const PdtGemm* g);
 // Number of K slices the dispatcher would like for this NT / NN problem (1 = none): small outputs (few tiles for

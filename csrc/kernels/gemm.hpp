@@ -28,7 +28,11 @@ enum GemmEpilogue : int {
 };
 using GemmArgs = PdtGemm;
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS>
+// STAGES: depth of the LDS ring of K-tiles.  2 = double buffer (the next K-tile is fetched while this one is
+// multiplied; small enough for two workgroups per CU with 128x128 tiles).  4 = three K-tiles in flight and one counted
+// wait per K-tile: for launches with about one workgroup per CU or fewer (short micro-batches), where nothing else
+// on the CU hides the ~2 us a K-tile takes from HBM / L2 to LDS.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS, int STAGES = 2>
 struct GemmKernel {
   static constexpr int NT = WAVES_M * WAVES_N * 64;
   static constexpr int BK = 64;
@@ -36,7 +40,8 @@ struct GemmKernel {
   static constexpr int FM = WTM / 16, FN = WTN / 16;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static_assert(STAGES == 2 || STAGES == 4, "ring depth");
   static constexpr int A_PASSES = A_BYTES / (NT * 16), B_PASSES = B_BYTES / (NT * 16);
   static_assert(WTN == 64, "staged epilogue assumes 64 output columns per wave");
   static_assert(A_BYTES % (NT * 16) == 0 && B_BYTES % (NT * 16) == 0, "tile/threads mismatch");
@@ -322,19 +327,7 @@ struct GemmKernel {
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    la.issue(smem, 0, klen, wave);
-    lb.issue(smem + A_BYTES, 0, klen, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      char* st = smem + cur * STAGE_BYTES;
-      if (kt + 1 < nkt) {
-        char* nx = smem + (cur ^ 1) * STAGE_BYTES;
-        la.issue(nx, kt + 1, klen, wave);
-        lb.issue(nx + A_BYTES, kt + 1, klen, wave);
-      }
+    auto multiply = [&](const char* st) {  // one K-tile from the ring slot `st`
       const char* ia = st;
       const char* ib = st + A_BYTES;
 #pragma unroll
@@ -354,9 +347,44 @@ struct GemmKernel {
             // D[n][m] => lane holds m = lane&15 and 4 consecutive n = 4*(lane>>4)+r
             acc[i][j] = Half16<T>::mfma(fb[j], fa[i], acc[i][j]);
       }
+    };
+    if (STAGES == 2) {
+      la.issue(smem, 0, klen, wave);
+      lb.issue(smem + A_BYTES, 0, klen, wave);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      cur ^= 1;
+      int cur = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) {
+          char* nx = smem + (cur ^ 1) * STAGE_BYTES;
+          la.issue(nx, kt + 1, klen, wave);
+          lb.issue(nx + A_BYTES, kt + 1, klen, wave);
+        }
+        multiply(smem + cur * STAGE_BYTES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      // K-tiles kt .. kt+STAGES-2 are in flight when tile kt is needed.  Every K-tile costs a wave the same number of
+      // DMA instructions - tiles past the end of K are issued too, with out-of-range offsets (they return zeros at
+      // once) - so the wait for tile kt is always "all but the newest (STAGES-2) tiles' worth": one immediate count.
+      constexpr int PER_TILE = A_PASSES + B_PASSES;
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s) {
+        la.issue(smem + s * STAGE_BYTES, s, klen, wave);
+        lb.issue(smem + s * STAGE_BYTES + A_BYTES, s, klen, wave);
+      }
+      for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_TILE) : "memory");
+        __syncthreads();  // tile kt has landed for every wave, and every wave is done reading tile kt-1 ...
+        char* nx = smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;  // ... whose slot takes tile kt+STAGES-1
+        la.issue(nx, kt + STAGES - 1, klen, wave);
+        lb.issue(nx + A_BYTES, kt + STAGES - 1, klen, wave);
+        multiply(smem + (kt % STAGES) * STAGE_BYTES);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing zero-fills: the epilogue reuses the ring)
+      __syncthreads();
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -369,7 +397,10 @@ struct GemmKernel {
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int n = n0 + wn * WTN + j * 16 + lg * 4;
-          if (m < g.M && n < g.N) *reinterpret_cast<float4v*>(slab + (size_t)m * g.ldc + n) = acc[i][j];
+          if (m < g.M && n < g.N) {
+            float4v* dst = reinterpret_cast<float4v*>(slab + (size_t)m * g.ldc + n);
+            *dst = g.slab_accumulate ? *dst + acc[i][j] : acc[i][j];
+          }
         }
       }
       return;
@@ -380,9 +411,9 @@ struct GemmKernel {
   }
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool AKS, bool BKS, int STAGES = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmArgs g) {
-  GemmKernel<T, BM, BN, WAVES_M, WAVES_N, AKS, BKS>::run(g);
+  GemmKernel<T, BM, BN, WAVES_M, WAVES_N, AKS, BKS, STAGES>::run(g);
 }
 
 }  // namespace pdt

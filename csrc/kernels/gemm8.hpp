@@ -322,7 +322,10 @@ struct Gemm8 {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + lg * 4;
-          if (m < ge.M && n < ge.N) *reinterpret_cast<float4v*>(slab + (size_t)m * ge.ldc + n) = acc[i][j];
+          if (m < ge.M && n < ge.N) {
+            float4v* dst = reinterpret_cast<float4v*>(slab + (size_t)m * ge.ldc + n);
+            *dst = ge.slab_accumulate ? *dst + acc[i][j] : acc[i][j];
+          }
         }
       }
     } else {

@@ -28,14 +28,21 @@ static int choose_tile(int layout, int tile, const PdtGemm* g) {
   // 128x128 kernel, two workgroups per CU, is 20-30 % ahead); for weight gradients (split-K fills the CUs
   // whatever the tile count) it wins from K = 8192 tokens on, for a 1024x1024 output only from 32768
   const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
+  // 128x128 tiles: with at most ~1.25 workgroups per CU (short micro-batches: 1024 tokens give 64-256 tiles) the
+  // 4-deep K-tile ring, otherwise the double-buffered kernel at two workgroups per CU.  In place in a BERT-large
+  // step of 12 x 8 samples the ring is worth 5.6 % (915 -> 967 samples/s) - operands come from HBM there; in a
+  // back-to-back micro-benchmark, where they sit in L2, it is not.  PDT_GEMM_DEEP=<tiles> moves the bound (0: never).
+  static const int deep = [] { const char* e = getenv("PDT_GEMM_DEEP"); return e ? atoi(e) : 320; }();
+  const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128);
+  const int small = (deep > 0 && t128 <= deep) ? 3 : 0;
   if (layout == PDT_GEMM_TN)
-    return (g->M >= 256 && g->N >= 256 && g->K >= 8192 && (t256 >= 32 || g->K >= 32768)) ? 2 : 0;
-  return t256 >= 192 ? 2 : 0;
+    return (g->M >= 256 && g->N >= 256 && g->K >= 8192 && (t256 >= 32 || g->K >= 32768)) ? 2 : small;
+  return t256 >= 192 ? 2 : small;
 }
 
 // K split of a weight gradient: fills g->splits / g->k_per_split (g->splits <= 0: choose)
 static void plan_tn(int tile, PdtGemm* g) {
-  const int bt = tile == 0 ? 128 : 256;
+  const int bt = (tile == 0 || tile == 3) ? 128 : 256;
   const int tiles = ((g->M + bt - 1) / bt) * ((g->N + bt - 1) / bt);
   const int ktiles = (g->K + 63) / 64;
   if (g->splits <= 0) {
@@ -44,6 +51,10 @@ static void plan_tn(int tile, PdtGemm* g) {
     int s = target / tiles;
     s = s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s);
     if (s > ktiles) s = ktiles;
+    // a short K (micro-batches of up to 2048 tokens) on the ring kernel is not split at all: the tile goes
+    // straight into the gradient (api.h: slab_accumulate) and the launch of a reduction kernel is saved - these
+    // steps are bound by the number of launches, not by idle CUs
+    if (tile == 3 && ktiles <= 32) s = 1;
     g->splits = s;
   }
   const int kt_per = (ktiles + g->splits - 1) / g->splits;
@@ -65,6 +76,14 @@ extern "C" int pdt_gemm_persist_mode(void) {
 extern "C" void pdt_gemm_set_persist_mode(int mode) { g_persist_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
 // number of fp32 slabs a weight-gradient GEMM of this shape will write (what the caller must allocate)
+// K split of forward / dgrad GEMMs with few output tiles (pdt_gemm_splits): on by default - a lone short micro-batch
+// is latency-bound and a split K shortens every GEMM of the dependent chain (BERT-large, batch 8: 809 vs 745
+// samples/s).  Off while two micro-batches are in flight on two streams (Engine.accumulate): the second stream
+// fills the idle CUs, and the saved epilogue launches count for more (12 x 8: 1262 vs 1217 samples/s).
+static int g_split_fwd = 1;
+extern "C" void pdt_gemm_set_split_mode(int on) { g_split_fwd = on ? 1 : 0; }
+extern "C" int pdt_gemm_split_mode(void) { return g_split_fwd; }
+
 extern "C" int pdt_gemm_tn_splits(int tile, const PdtGemm* g) {
   PdtGemm c = *g;
   pdt::plan_tn(pdt::choose_tile(PDT_GEMM_TN, tile, &c), &c);
@@ -80,9 +99,10 @@ extern "C" int pdt_gemm_splits(int layout, int tile, const PdtGemm* g) {
   using namespace pdt;
   if (layout == PDT_GEMM_TN || g->colsum != nullptr || g->epi == PDT_EPI_SLAB_F32) return 1;
   const int64_t t256 = (int64_t)((g->M + 255) / 256) * ((g->N + 255) / 256);
-  if (tile > 0 || (tile < 0 && t256 >= 192)) return 1;  // only the 128x128 kernel takes this path
+  if ((tile > 0 && tile != 3) || (tile < 0 && t256 >= 192)) return 1;  // only the 128x128 kernels take this path
   const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128);
   const int ktiles = (g->K + 63) / 64;
+  if (!g_split_fwd) return 1;
   int s = (int)((2 * kNumCU) / t128);
   if (s > ktiles / 16) s = ktiles / 16;
   if (s > 8) s = 8;
@@ -103,6 +123,7 @@ extern "C" int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* strea
   if (layout == PDT_GEMM_TN) {
     if (g->epi != PDT_EPI_SLAB_F32) return -5;
     plan_tn(tile, g);
+    if (g->slab_accumulate && g->splits != 1) return -5;
     return pdt_gemm_tn(dtype, tile, g, stream);
   }
   // each operand layout carries the epilogues of its role (forward: bias family; data gradient: GELU-grad

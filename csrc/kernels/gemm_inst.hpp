@@ -73,10 +73,10 @@ static int launch_split(PdtGemm& g, hipStream_t stream, LaunchFn&& launch_gemm) 
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_tile(PdtGemm& g, hipStream_t stream) {
-  using K = GemmKernel<T, BM, BN, WM, WN, PDT_AKS, PDT_BKS>;
-  auto kern = gemm_kernel<T, BM, BN, WM, WN, PDT_AKS, PDT_BKS>;
+  using K = GemmKernel<T, BM, BN, WM, WN, PDT_AKS, PDT_BKS, STAGES>;
+  auto kern = gemm_kernel<T, BM, BN, WM, WN, PDT_AKS, PDT_BKS, STAGES>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
@@ -160,6 +160,7 @@ template <typename T>
 static int launch_dtype(int tile, PdtGemm& g, hipStream_t stream) {
   if (tile == 2) return launch_pingpong<T>(g, stream);
   if (tile == 1) return launch_tile<T, 256, 256, 2, 4>(g, stream);
+  if (tile == 3) return launch_tile<T, 128, 128, 2, 2, 4>(g, stream);
   return launch_tile<T, 128, 128, 2, 2>(g, stream);
 }
 

@@ -213,6 +213,12 @@ void gemm_tn_into(const Tensor& A, const Tensor& B, Tensor& G, bool accumulate, 
   g.epi = PDT_EPI_SLAB_F32;
   g.splits = splits;
   g.splits = pdt_gemm_tn_splits(tile, &g);
+  if (g.splits == 1) {  // K is not split: the kernel writes (or adds to) the gradient itself
+    g.C = G.data_ptr();
+    g.slab_accumulate = accumulate ? 1 : 0;
+    check(pdt_gemm(dt_code(A), PDT_GEMM_TN, tile, &g, cur_stream()), "gemm_tn");
+    return;
+  }
   Tensor slab = at::empty({(int64_t)g.splits * M * N}, G.options());
   g.C = slab.data_ptr();
   check(pdt_gemm(dt_code(A), PDT_GEMM_TN, tile, &g, cur_stream()), "gemm_tn");
@@ -630,14 +636,18 @@ void bind_wordpiece(py::module_& m);  // wordpiece.cpp
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "gfx950 kernels + native runtime of pytorch_distributed_training_amd";
   // (the trailing `sample_ids` arguments: optional int32 [B] global sample ids for sample-keyed dropout, see PdtRng)
-  m.def("layer_forward", &layer_forward);
-  m.def("layer_backward", &layer_backward);
-  m.def("embed_forward", &embed_forward);
-  m.def("embed_backward", &embed_backward);
-  m.def("dense_tanh_forward", &dense_tanh_forward);
-  m.def("dense_backward", &dense_backward);
-  m.def("head_forward", &head_forward);
-  m.def("head_backward", &head_backward);
+  // The GIL is released while a call issues its launches (25-30 HIP calls for a layer's backward): a second Python
+  // thread can enqueue the next micro-batch's forward on its own stream meanwhile (Engine.accumulate) - short
+  // micro-batches are bound by the rate at which ONE host thread can launch kernels.
+  using nogil = py::call_guard<py::gil_scoped_release>;
+  m.def("layer_forward", &layer_forward, nogil());
+  m.def("layer_backward", &layer_backward, nogil());
+  m.def("embed_forward", &embed_forward, nogil());
+  m.def("embed_backward", &embed_backward, nogil());
+  m.def("dense_tanh_forward", &dense_tanh_forward, nogil());
+  m.def("dense_backward", &dense_backward, nogil());
+  m.def("head_forward", &head_forward, nogil());
+  m.def("head_backward", &head_backward, nogil());
   m.def("dropout16", &dropout16);
   m.def("adamw_step", &adamw_step);
   m.def("grad_check", &grad_check);
@@ -666,6 +676,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_gemm_persistent", [](int64_t mode) { pdt_gemm_set_persist_mode((int)mode); },
         "persistent launches of the ping-pong GEMM: 0 never, 1 from 4 tiles per workgroup (default), 2 from 2");
   m.def("gemm_persistent_mode", [] { return pdt_gemm_persist_mode(); });
+  m.def("set_gemm_split_k", [](bool on) { pdt_gemm_set_split_mode(on ? 1 : 0); },
+        "K split of forward / dgrad GEMMs with few output tiles: on (default) for latency-bound lone micro-batches, off "
+        "while two micro-batches overlap on two streams");
+  m.def("gemm_split_k", [] { return pdt_gemm_split_mode() != 0; });
   m.def("set_debug_sync", [](bool on) { g_debug_sync = on; },
         "drain the device after every native launch and report a fault at the op that caused it");
   m.def("debug_sync_count", [] { return g_debug_sync_count; });

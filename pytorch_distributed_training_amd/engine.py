@@ -198,6 +198,98 @@ class Engine:
                     st.enter_context(m.no_sync())
             yield
 
+    def accumulate(self, model: nn.Module, batches, overlap: Optional[bool] = None):
+        """Forward + backward of one accumulation window (`batches` = its micro-batches, loss / len(batches) each, the
+        gradient all-reduce armed for the last one only); returns the detached per-micro-batch losses.
+
+        With ``overlap`` (default: on for the native GPU path) the window is software-pipelined over two HIP
+        streams: the forward of micro-batch i+1 is enqueued before the backward of micro-batch i and runs next to
+        it.  The two are independent - the weights only change at the optimizer step - and with the reference's
+        8-sample micro-batches (/root/reference/test_data_parallelism.py:90-93) neither fills the GPU on its own:
+        a 1024-token GEMM has 64-256 output tiles for 256 CUs.  Every micro-batch lives on ONE stream (forward
+        and backward, which is also where autograd runs a node's backward), consecutive backward passes are
+        ordered by events because they accumulate into the same gradient arena, and the caller's stream waits for
+        both before the optimizer step.  The arithmetic is that of the plain loop."""
+        n = len(batches)
+        dp = model if isinstance(model, DataParallel) else None
+        if overlap is None:
+            overlap = self.native and self.device.type == "cuda" and os.environ.get("PDT_OVERLAP_MICRO", "1") != "0"
+        if dp is not None:
+            auto_arm, dp.auto_arm = dp.auto_arm, False
+        losses = []
+        split_k = None
+        try:
+            if not overlap or n < 2:
+                for i, b in enumerate(batches):
+                    out = model(**b)
+                    if dp is not None:
+                        dp.require_sync = i == n - 1
+                        if i == n - 1:
+                            dp.prepare_backward()
+                    self.backward(out.loss / n)
+                    losses.append(out.loss.detach())
+                return losses
+            main = torch.cuda.current_stream(self.device)
+            if getattr(self, "_alt_stream", None) is None:
+                self._alt_stream = torch.cuda.Stream(device=self.device)
+            streams = [main, self._alt_stream]
+            start = torch.cuda.Event()
+            start.record(main)
+            self._alt_stream.wait_event(start)  # parameters / batches produced on the caller's stream so far
+            for b in batches[1::2]:
+                for t in b.values():
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(self._alt_stream)
+
+            def forward(i):
+                with torch.cuda.stream(streams[i % 2]):
+                    out = model(**batches[i])
+                    loss = out.loss / n
+                    if self.scaler.enabled:
+                        loss = loss * self.scaler.scale_tensor().to(loss.dtype)
+                    return out, loss
+
+            # The forward of the next micro-batch is issued by a second host thread while this one issues the
+            # backward: the native ops release the GIL around their launches, and with 8-sample micro-batches the
+            # step is bound by how fast ONE thread can launch ~1000 kernels per micro-batch, not by the GPU.
+            if getattr(self, "_fwd_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._fwd_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="pdt-forward")
+            threaded = os.environ.get("PDT_OVERLAP_THREAD", "1") != "0"
+            from .ops import native as _native
+
+            split_k = _native().gemm_split_k()
+            _native().set_gemm_split_k(False)  # two chains share the CUs: fewer launches beat shorter GEMMs here
+            cur, done = forward(0), None
+            for i in range(n):
+                nxt = None
+                if i + 1 < n:  # started BEFORE backward(i): runs concurrently with it
+                    nxt = self._fwd_pool.submit(forward, i + 1) if threaded else forward(i + 1)
+                s = streams[i % 2]
+                with torch.cuda.stream(s):
+                    if done is not None:
+                        s.wait_event(done)  # backward passes accumulate into one arena: strictly one after the other
+                    if dp is not None:
+                        dp.require_sync = i == n - 1
+                        if i == n - 1:
+                            dp.prepare_backward()
+                    cur[1].backward()
+                    done = torch.cuda.Event()
+                    done.record(s)
+                losses.append(cur[0].loss.detach())
+                cur = nxt.result() if (threaded and nxt is not None) else nxt
+            tail = torch.cuda.Event()  # the caller's stream continues after everything on the second stream
+            tail.record(self._alt_stream)
+            main.wait_event(tail)
+            return losses
+        finally:
+            if split_k is not None:
+                _native().set_gemm_split_k(split_k)
+            if dp is not None:
+                dp.auto_arm = auto_arm
+                dp.require_sync = True
+
     def unwrap_model(self, model: nn.Module) -> nn.Module:
         return model.module if isinstance(model, DataParallel) else model
 

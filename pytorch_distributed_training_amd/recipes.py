@@ -136,7 +136,6 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     logger = StepLogger(engine.is_main_process, cfg.log_every, cfg.log_file,
                         samples_per_step=micro_bs * accum * engine.num_processes)
     dog = StepWatchdog(float(os.environ.get("PDT_WATCHDOG_S", "0")), engine.process_index)
-    tail = micro_per_epoch % accum  # micro-batches of the partial window that ends an epoch (0: none)
     # PDT_COMM_TIMING=1: the log line carries the gradient-communication time that backward did not hide
     comm_extra = (lambda: {"comm_exposed_ms": model.comm_exposed_ms()}) if getattr(model, "measure_exposed", False) else None
     last_metric: dict = {}
@@ -146,34 +145,38 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
         model.train()
         if hasattr(train_dl, "set_epoch"):
             train_dl.set_epoch(epoch)
-        pending = 0
+        pending = []
         first = start_micro if epoch == start_epoch else 0
         if first and hasattr(train_dl, "skip_batches"):
             train_dl.skip_batches(first)
         for step, batch in enumerate(train_dl, start=first):
             window = accum
-            if cfg.compat:
-                fire = step % accum == 0
-                sync_ctx = _Null()  # the reference's DP script reduces on every micro-batch
-            else:
-                pending += 1
-                fire = pending == accum or step == micro_per_epoch - 1
-                sync_ctx = _Null() if fire else engine.no_sync(model)
-                if tail and step >= micro_per_epoch - tail:
-                    window = tail  # the flushed partial window is a mean over its own micro-batches
             logger.add_tokens(batch["input_ids"].numel() * engine.num_processes)
-            with sync_ctx:
+            if cfg.compat:
+                # the reference's DP script: every micro-batch is reduced, the optimizer fires when step % accum == 0
+                fire = step % accum == 0
                 with trace_range("forward"):
                     outputs = model(**batch)
                     loss = outputs.loss / window
-                with trace_range("backward+reduce" if fire else "backward"):
+                with trace_range("backward+reduce"):
                     engine.backward(loss)
+            else:
+                # one accumulation window = `accum` micro-batches (the partial window that ends an epoch is a mean
+                # over its own micro-batches): forward / backward software-pipelined by Engine.accumulate, gradients
+                # reduced once, with the last backward
+                pending.append(batch)
+                fire = len(pending) == accum or step == micro_per_epoch - 1
+                if not fire:
+                    continue
+                window = len(pending)
+                with trace_range("window forward+backward+reduce"):
+                    loss = torch.stack(engine.accumulate(model, pending)).mean() / window
             if fire:
                 with trace_range("optimizer"):
                     optimizer.step()
                     lr_scheduler.step()
                     optimizer.zero_grad()
-                pending = 0
+                pending = []
                 global_step += 1
                 seed_step(cfg.seed, engine.process_index, global_step)
                 dog.heartbeat()
