@@ -115,6 +115,10 @@ def main() -> None:
     pool = [fixed_batch(micro, args.seq_len, vocab, eng.device, seed=1000 * eng.process_index + i,
                         first_id=eng.process_index * args.batch + (i % args.accum) * micro) for i in range(4)]
 
+    if os.environ.get("PDT_BENCH_NO_SAMPLE_IDS"):  # A/B aid: rank-keyed dropout streams instead of sample-keyed ones
+        for b in pool:
+            b.pop("sample_ids", None)
+
     def step(i: int) -> torch.Tensor:
         if args.accum > 1:
             # one accumulation window: micro-batch i+1's forward is enqueued next to micro-batch i's backward

@@ -147,9 +147,10 @@ struct GemmKernel {
   // ---- epilogue ------------------------------------------------------------------------------------
   // Math on 8 consecutive columns of one row.  `bias` holds the 8 bias values of these columns (zeros when the
   // epilogue has none), `ext` the 8 side-input values of this row: aux for MUL_DGELU, res for *_RES.
+  // `drow`: the row the dropout counters of row m derive from (drop_row(g.rng, m); only read by BIAS_DROP_RES)
   template <int epi>
   static __device__ __forceinline__ void epilogue8(const GemmArgs& g, int m, int n, float (&v)[8], const float (&bias)[8],
-                                                   const short8& ext, const DropKey& dk) {
+                                                   const short8& ext, const DropKey& dk, uint32_t drow) {
     if (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_TANH) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += bias[i];
@@ -170,7 +171,7 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] *= d[i];
     }
     if (epi == EPI_BIAS_DROP_RES && g.drop_thr != 0) {
-      const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_row(g.rng, m) * g.N + n) >> 3, g.drop_thr);
+      const uint32_t keep = drop_keep8(dk, ((uint64_t)drow * g.N + n) >> 3, g.drop_thr);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * g.drop_scale : 0.0f;
     }
@@ -226,6 +227,11 @@ struct GemmKernel {
     const T* ext = dgelu ? (const T*)g.aux : (const T*)g.res;
     const int ldx = dgelu ? g.ldaux : g.ldr;
     short8 xin[2][4];
+    // sample-keyed dropout (PdtRng::sample_ids): when the sequence length is a multiple of 32 the 32 rows of a staged
+    // block pair belong to ONE sample, so the id lookup is wave-uniform (a scalar load) and a row's dropout row is
+    // m + offset; other lengths look the id up per row
+    const bool keyed = epi == EPI_BIAS_DROP_RES && g.drop_thr != 0 && g.rng.sample_ids != nullptr;
+    const bool keyed_uniform = keyed && (g.rng.seq & 31u) == 0;
     auto fetch = [&](int ip, short8(&dst)[4]) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -235,10 +241,23 @@ struct GemmKernel {
       }
     };
     fetch(0, xin[0]);
+    uint32_t drow_offs[NIP];  // (wave-uniform: the id loads are issued together, ahead of the loop that uses them)
+#pragma unroll
+    for (int ip = 0; ip < NIP; ++ip) {
+      drow_offs[ip] = 0;
+      if (keyed_uniform) {
+        const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(mbase(ip));
+        if (m32 < (uint32_t)g.M) {
+          const uint32_t b = __umulhi(m32, g.rng.seq_magic);
+          drow_offs[ip] = (uint32_t)g.rng.sample_ids[b] * 512u - b * g.rng.seq;
+        }
+      }
+    }
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ip = 0; ip < NIP; ++ip) {
       if (ip + 1 < NIP) fetch(ip + 1, xin[(ip + 1) & 1]);
+      const uint32_t drow_off = drow_offs[ip];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = h * 16 + lm;
@@ -257,7 +276,9 @@ struct GemmKernel {
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const int m = mbase(ip) + row;
         if (m < g.M && n_ok) {
-          epilogue8<epi>(g, m, n, v, bias, xin[ip & 1][it], dk);
+          uint32_t drow = (uint32_t)m;
+          if (epi == EPI_BIAS_DROP_RES && keyed) drow = keyed_uniform ? (uint32_t)m + drow_off : drop_row(g.rng, m);
+          epilogue8<epi>(g, m, n, v, bias, xin[ip & 1][it], dk, drow);
           if (g.colsum) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) cs[i] += v[i];

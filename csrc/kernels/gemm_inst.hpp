@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(PdtGemm g) {
       unpack8<T>(*reinterpret_cast<const short8*>((const T*)g.bias + n), bias);
     short8 x = short8{0, 0, 0, 0, 0, 0, 0, 0};
     if (dgelu || EPI == EPI_BIAS_DROP_RES || EPI == EPI_ADD_RES) x = *reinterpret_cast<const short8*>(ext + (size_t)m * ldx + n);
-    K::template epilogue8<EPI>(g, m, n, v, bias, x, dk);
+    K::template epilogue8<EPI>(g, m, n, v, bias, x, dk, EPI == EPI_BIAS_DROP_RES ? drop_row(g.rng, (uint32_t)m) : 0u);
   }
 }
 

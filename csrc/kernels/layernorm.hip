@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const float invH = 1.0f / H;
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    // (looked up here, next to the row loads, not where the mask is drawn: the sample-id load is a dependent access)
+    const uint32_t drow = (ddrop && drop_thr != 0) ? drop_row(rng, (uint32_t)row) : (uint32_t)row;
     float g[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         *reinterpret_cast<short8*>(dx + (size_t)row * H + c * 8) = pack8<T>(o);
         if (ddrop) {
           if (drop_thr != 0) {
-            const uint32_t keep = drop_keep8(dk, ((uint64_t)drop_row(rng, row) * H + c * 8) >> 3, drop_thr);
+            const uint32_t keep = drop_keep8(dk, ((uint64_t)drow * H + c * 8) >> 3, drop_thr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = ((keep >> j) & 1u) ? o[j] * drop_scale : 0.f;
           }
