@@ -62,6 +62,8 @@ def main() -> None:
     ap.add_argument("--comm", default=None, choices=[None, "c10d", "rccl"],
                     help="gradient all-reduce and pipeline send/recv through the framework's own RCCL communicator and "
                          "communication stream (rccl, default) or through torch's RCCL process group (c10d)")
+    ap.add_argument("--comm-algo", default=None, choices=[None, "allreduce", "rs_ag"],
+                    help="gradient buckets as one all-reduce (default) or as reduce-scatter + all-gather (own RCCL communicator)")
     ap.add_argument("--pp", type=int, default=1, choices=[1, 2],
                     help="2 = every data-parallel replica is a 2-stage layer-split pipeline over a pair of GPUs (1F1B over "
                          "send/recv); N GPUs = N/2 replicas.  The per-replica batch is 2 x --batch, so the work per GPU is "
@@ -79,6 +81,8 @@ def main() -> None:
         faulthandler.dump_traceback_later(float(os.environ["PDT_HANG_DUMP"]), exit=True)
     if args.batch is None:
         args.batch = max(1, 131072 // args.seq_len)
+    if args.comm_algo:
+        os.environ["PDT_COMM_ALGO"] = args.comm_algo
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_self_launch(args.gpus))
@@ -108,6 +112,7 @@ def main() -> None:
 
         model = DataParallel(model, model.arena, None, comm, comm_backend=args.comm)
         eng._models[-1] = model
+        optimizer.optimizer.grads_checked_by_reducer = model.attach_scaler(eng.scaler)
     sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
     model.train()
     micro = args.batch // args.accum
@@ -197,6 +202,7 @@ def main() -> None:
                        "micro_batches": args.accum, "seq_len": args.seq_len,
                        "parallelism": f"dp{world}" + (" (1-rank RCCL rehearsal)" if args.rehearse_dp else ""),
                        "comm_backend": getattr(model, "backend_label", "none"),
+                       "comm_algo": os.environ.get("PDT_COMM_ALGO", "allreduce"),
                        "gemm_persistent_mode": _persist_mode(),
                        "hip_graph": bool(args.graph),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include "../kernels/api.h"
+
 #include <cstdlib>
 #include <cstring>
 
@@ -160,6 +162,15 @@ void RcclComm::reduce_scatter_async(const at::Tensor& out, const at::Tensor& in,
                              average ? ncclAvg : ncclSum, comm_, stream_));
   ++launches_;
   bytes_ += in.numel() * in.element_size();
+}
+
+void RcclComm::check_finite_async(const at::Tensor& t, const at::Tensor& scale_state) {
+  check_tensor(t);
+  TORCH_CHECK(t.scalar_type() == at::kFloat, "check_finite: fp32 gradients expected");
+  TORCH_CHECK(scale_state.is_cuda() && scale_state.scalar_type() == at::kFloat && scale_state.numel() >= 4,
+              "check_finite: scale_state is float[4] on the GPU");
+  const int e = pdt_grad_check(t.data_ptr<float>(), t.numel(), scale_state.data_ptr<float>(), stream_);
+  TORCH_CHECK(e == 0, "grad_check launch failed: ", e);
 }
 
 void RcclComm::p2p_async(const std::vector<int64_t>& kinds, const std::vector<at::Tensor>& tensors,

@@ -47,6 +47,9 @@ class RcclComm {
   void broadcast_async(const at::Tensor& t, int64_t root);
   void all_gather_async(const at::Tensor& out, const at::Tensor& in);
   void reduce_scatter_async(const at::Tensor& out, const at::Tensor& in, bool average);
+  // enqueue the non-finite check of fp32 `t` on the communication stream: scale_state[2] = 1 if any element is inf / NaN
+  // (the loss scaler's overflow flag; run right behind a bucket's all-reduce it overlaps backward like the all-reduce)
+  void check_finite_async(const at::Tensor& t, const at::Tensor& scale_state);
   // a group of sends / receives that must progress together: kinds[i] 0 = send, 1 = recv
   void p2p_async(const std::vector<int64_t>& kinds, const std::vector<at::Tensor>& tensors, const std::vector<int64_t>& peers);
 

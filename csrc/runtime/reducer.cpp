@@ -23,6 +23,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace py = pybind11;
@@ -69,6 +70,12 @@ class GradBucketReducer {
     // a single-GPU test box)
     const char* force = std::getenv("PDT_FORCE_COLLECTIVES");
     force_ = force && force[0] == '1';
+    // PDT_COMM_ALGO=rs_ag (own communicator only): a bucket is reduced as reduce-scatter + all-gather, both in place -
+    // the two halves of an all-reduce as separate RCCL calls, each rank owning the 1/world shard at its rank offset.
+    // On a fully connected xGMI node every rank then exchanges one shard with each of its 7 peers per phase; which of
+    // the two forms RCCL runs faster on a given node is a measurement (bench.py --comm-algo), not a given.
+    const char* algo = std::getenv("PDT_COMM_ALGO");
+    rs_ag_ = rccl_ && algo && std::string(algo) == "rs_ag";
     reset();
   }
 
@@ -146,6 +153,14 @@ class GradBucketReducer {
     for (auto& w : ws) w->wait();
   }
 
+  // Loss-scaler state {scale, tracker, found_inf, ...} of an fp16 run: with the framework's own communicator every
+  // bucket is checked for inf / NaN on the communication stream right behind its all-reduce - on the REDUCED
+  // values, so every rank takes the same decision - instead of in one pass over the whole arena after backward.
+  void set_overflow_state(Tensor state) { overflow_state_ = std::move(state); }
+  bool checks_overflow() const {
+    return rccl_ && overflow_state_.defined() && !comm_dtype_.has_value() && (world_ > 1 || force_);
+  }
+
   int64_t num_buckets() const { return nb_; }
   int64_t world_size() const { return world_; }
   std::vector<int64_t> launch_order() const { return order_; }
@@ -189,7 +204,14 @@ class GradBucketReducer {
     if (rccl_) {
       // ordered after the kernels that produced the bucket (everything enqueued on the compute stream so far)
       rccl_->fork();
-      rccl_->all_reduce_async(buf, average_);
+      if (rs_ag_ && buf.numel() % world_ == 0) {
+        Tensor shard = buf.narrow(0, (buf.numel() / world_) * rccl_->rank(), buf.numel() / world_);
+        rccl_->reduce_scatter_async(shard, buf, average_);
+        rccl_->all_gather_async(buf, shard);
+      } else {
+        rccl_->all_reduce_async(buf, average_);
+      }
+      if (checks_overflow()) rccl_->check_finite_async(views_[b], overflow_state_);
       launched_any_ = true;
     } else {
       c10d::AllreduceOptions opts;
@@ -203,12 +225,13 @@ class GradBucketReducer {
 
   PG pg_;
   std::shared_ptr<pdt::RcclComm> rccl_;
-  Tensor arena_;
+  Tensor arena_, overflow_state_;
   std::vector<int64_t> bounds_, expected_;
   bool average_;
   c10::optional<at::ScalarType> comm_dtype_;
   int nb_ = 0, world_ = 1, next_ = 0;
   bool is_nccl_ = false, host_staged_ = false, sync_ = true, active_ = false, force_ = false, launched_any_ = false;
+  bool rs_ag_ = false;
   std::vector<Tensor> views_, staged_;
   std::vector<int64_t> ready_, order_;
   std::vector<c10::intrusive_ptr<c10d::Work>> works_;
@@ -230,6 +253,8 @@ void bind_reducer(py::module_& m) {
       .def("finish", &GradBucketReducer::finish, py::call_guard<py::gil_scoped_release>())
       .def("broadcast", &GradBucketReducer::broadcast, py::arg("tensor"), py::arg("root") = 0,
            py::arg("chunk_elems") = (int64_t)16 << 20, py::call_guard<py::gil_scoped_release>())
+      .def("set_overflow_state", &GradBucketReducer::set_overflow_state)
+      .def("checks_overflow", &GradBucketReducer::checks_overflow)
       .def("num_buckets", &GradBucketReducer::num_buckets)
       .def("world_size", &GradBucketReducer::world_size)
       .def("launch_order", &GradBucketReducer::launch_order)

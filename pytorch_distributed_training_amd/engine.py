@@ -175,6 +175,9 @@ class Engine:
             fused = FusedAdamW(self._arena, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"],
                                weight_decay=g["weight_decay"], correct_bias=g.get("correct_bias", True),
                                scaler=self.scaler)
+            dps = [m for m in self._models if isinstance(m, DataParallel) and m.arena is self._arena]
+            # (the overflow check rides behind the bucket all-reduces when the reducer can do it)
+            fused.grads_checked_by_reducer = bool(dps) and all(m.attach_scaler(self.scaler) for m in dps)
             return EngineOptimizer(fused, self)
         return EngineOptimizer(optimizer, self)
 

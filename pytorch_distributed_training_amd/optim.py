@@ -65,6 +65,9 @@ class FusedAdamW:
         self.betas, self.eps, self.weight_decay, self.correct_bias = betas, eps, weight_decay, correct_bias
         self.scaler = scaler or LossScaler(dev, enabled=False)
         self.grad_divisor = 1.0  # extra division folded into the un-scaling (not used by default)
+        # True: the data-parallel reducer already flags non-finite values bucket by bucket, on the reduced gradients
+        # (parallel/dp.py attach_scaler) - no separate pass over the arena here
+        self.grads_checked_by_reducer = False
         self.param_groups = [{"lr": lr, "initial_lr": lr}]  # scheduler-facing, mirrors torch optimizers
         self._host_lr = lr
 
@@ -92,11 +95,12 @@ class FusedAdamW:
             from .ops import native
 
             C = native()
-            check = self.scaler.enabled
-            if check and overflow_group is not None:
+            check = self.scaler.enabled and not self.grads_checked_by_reducer
+            if self.scaler.enabled and overflow_group is not None:
                 import torch.distributed as dist
 
-                C.grad_check(a.grad, self.scaler.state)
+                if check:
+                    C.grad_check(a.grad, self.scaler.state)
                 flag = self.scaler.state[2:3]
                 if dist.get_backend(overflow_group) == "gloo":
                     # single-GPU rehearsal (ranks share the card, gloo transport): stage the flag through the host

@@ -181,6 +181,14 @@ class DataParallel(nn.Module):
                                f"(arena elements / parameters / buckets / layout hash: "
                                f"{[t.tolist() for t in every]})")
 
+    def attach_scaler(self, scaler) -> bool:
+        """Let the reducer check every reduced bucket for inf / NaN on the communication stream (fp16 runs on the
+        framework's own communicator).  True if it will, i.e. the optimizer can skip its own pass over the arena."""
+        if scaler is None or not scaler.enabled or not hasattr(self.reducer, "set_overflow_state"):
+            return False
+        self.reducer.set_overflow_state(scaler.state)
+        return bool(self.reducer.checks_overflow())
+
     def rccl_ranks(self) -> int:
         """Ranks that exchange this model's gradients over RCCL: what RCCL itself reports for the framework's own
         communicator (ncclCommCount), the group size for torch's "nccl" group, 0 for gloo."""

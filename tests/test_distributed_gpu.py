@@ -202,9 +202,31 @@ def grads(mode):
 g0 = grads(None)
 g1 = grads(("rccl", None))
 g2 = grads(("rccl", torch.bfloat16))
-assert g0.abs().sum() > 0 and (g1 - g0).abs().max() <= 1e-5 * g0.abs().max()   # (embedding rows: fp32 atomics)
+os.environ["PDT_COMM_ALGO"] = "rs_ag"      # buckets as reduce-scatter + all-gather (in place) instead of one all-reduce
+g3 = grads(("rccl", None))
+assert torch.equal(g3, g1)
+assert g0.abs().sum() > 0 and torch.equal(g1, g0)   # (every gradient reduction is deterministic)
 assert (g2 - g0).abs().max() <= 1e-2 * g0.abs().max() + 1e-6
 assert create_rccl_comm().collectives() >= 6
+# the loss scaler's overflow flag set bucket by bucket on the communication stream, behind each all-reduce
+def overflow_flag(loss_factor):
+    torch.manual_seed(0)
+    m = build_model("bert-tiny").cuda()
+    arena = ParamArena(m, torch.device("cuda"), torch.float16, min_bucket_elems=1 << 14)
+    m.enable_native(arena, seed=1)
+    m.train()
+    red, _, _ = make_reducer(None, arena, list(arena.bucket_segments), True, None, comm_backend="rccl")
+    state = torch.tensor([1.0, 0.0, 0.0, 0.0], device="cuda")
+    red.set_overflow_state(state)
+    assert red.checks_overflow()
+    seg_bucket = [s.bucket for s in arena.segments]
+    m.runtime.segment_done = lambda seg: red.mark_ready(seg_bucket[seg], 1)
+    red.begin(True)
+    (m(**b).loss * loss_factor).backward()
+    red.finish()
+    torch.cuda.synchronize()
+    return float(state[2])
+assert overflow_flag(1.0) == 0.0 and overflow_flag(1e30) == 1.0
 print("REDUCER_NATIVE_RCCL_OK")
 '''
     _run_snippet(code, "REDUCER_NATIVE_RCCL_OK")
