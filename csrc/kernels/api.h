@@ -24,6 +24,10 @@ typedef struct PdtRng {
   const int32_t* sample_ids;
   uint32_t seq;           // tokens per sample of the activation the kernel works on (1 for [B, H] tensors)
   uint32_t seq_magic;     // ceil(2^32 / seq): row / seq == umulhi(row, seq_magic) for row * seq < 2^32
+  // Unpadded (packed) activations [T, H], where a row's sample and position do not follow from its index: the
+  // dropout row of every row, precomputed (sample id * 512 + position; device, uint32 [T]).  Takes precedence over
+  // the (sample_ids, seq) rule for row-wise tensors; per-sample tensors and attention still use sample_ids.
+  const uint32_t* row_table;
 } PdtRng;
 
 // ---- GEMM -------------------------------------------------------------------------------------
@@ -135,15 +139,17 @@ int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, int H, float
 // ---- Attention -------------------------------------------------------------------------------------
 // qkv: 16-bit [B*S, 3H] (Q | K | V, head h at columns h*64 of each third); mask int32 [B,S];
 // kv_len int32 [B]; ctx 16-bit [B*S, H]; lse fp32 [B, A, S].  head_dim == 64, S <= 512.
-int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, void* ctx, float* lse,
-                 int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+// cu (nullable): int32 [B+1] first rows of the samples in a PACKED qkv / ctx [T, ...] (unpadded batch); S is then the
+// longest sequence, mask and kv_len are not read.
+int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu, void* ctx,
+                 float* lse, int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
 // dqkv 16-bit [B*S, 3H];  delta fp32 [B,A,S] scratch.  dbias (nullable, fp32 [B][3H]): per-sample column sums of
 // dqkv (finish with pdt_colsum_finish(dbias, B, 3H, 1, ...) to get the QKV bias gradient) - only available
 // when pdt_attn_bwd_fuses_dbias(S) is 1, otherwise pass null and reduce dqkv separately.
 int pdt_attn_bwd_fuses_dbias(int S);
-int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const void* ctx,
-                 const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias, int B, int S, int A,
-                 float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
+int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu,
+                 const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias, int B, int S,
+                 int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
 
 // ---- Classification head ------------------------------------------------------------------------------
 // logits[b][c] = dot(dropout(pooled[b]), W[c]) + bias[c]; loss[0] = mean CE.  pooled 16-bit [B,H];

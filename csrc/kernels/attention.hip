@@ -26,6 +26,10 @@ struct AttnArgs {
   const void* qkv;   // [B*S, 3H]
   const int32_t* mask;
   const int32_t* kv_len;
+  // Unpadded ("varlen") batches: cu[b] = first token row of sample b in the packed [T, ...] tensors, cu[B] = T; S is
+  // then the LONGEST sequence (grid extent, stride of lse / delta) and every key of a sample is valid (mask and
+  // kv_len are not read).  Null: padded [B, S] layout.
+  const int32_t* cu;
   void* ctx;         // fwd out [B*S, H]
   float* lse;        // [B, A, S]
   const void* octx;  // bwd: forward output
@@ -136,11 +140,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
-  const int S = a.S, ld = 3 * a.H;
-  const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
-  const int kvl = min(a.kv_len[b], S);
+  const int SM = a.S, ld = 3 * a.H;                    // SM: longest sequence (lse / delta stride)
+  const int row0 = a.cu ? a.cu[b] : b * SM;            // first token row of this sample
+  const int S = a.cu ? a.cu[b + 1] - row0 : SM;        // its length
+  const T* base = (const T*)a.qkv + (size_t)row0 * ld + h * HD;
+  const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int npb = (kvl + 31) >> 5;
-  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
+  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && (a.cu || a.mask[(size_t)b * SM + k] != 0)) ? 0.f : -INFINITY;
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
   const bool active = q0 < S;  // wave-uniform
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   l = quad_sum(l);
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   // a row whose keys are all masked has no probability mass: lse = +inf makes every recomputed p exactly 0
-  if (g == 0 && q < S) a.lse[(size_t)bh * S + q] = l > 0.f ? (m + __log2f(l)) * (1.0f / LOG2E) : INFINITY;
+  if (g == 0 && q < S) a.lse[(size_t)bh * SM + q] = l > 0.f ? (m + __log2f(l)) * (1.0f / LOG2E) : INFINITY;
   if (q < S) {
-    T* out = (T*)a.ctx + ((size_t)b * S + q) * a.H + h * HD;
+    T* out = (T*)a.ctx + ((size_t)row0 + q) * a.H + h * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       short4v pk;
@@ -243,13 +249,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
-  const int S = a.S, ld = 3 * a.H;
-  const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
-  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
-  const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
-  const int kvl = min(a.kv_len[b], S);
+  const int SM = a.S, ld = 3 * a.H;                    // SM: longest sequence (lse / delta stride)
+  const int row0 = a.cu ? a.cu[b] : b * SM;            // first token row of this sample
+  const int S = a.cu ? a.cu[b + 1] - row0 : SM;        // its length
+  const T* base = (const T*)a.qkv + (size_t)row0 * ld + h * HD;
+  const T* dob = (const T*)a.dctx + (size_t)row0 * a.H + h * HD;
+  const T* ob = (const T*)a.octx + (size_t)row0 * a.H + h * HD;
+  const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int npb = (kvl + 31) >> 5;
-  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && a.mask[(size_t)b * S + k] != 0) ? 0.f : -INFINITY;
+  for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && (a.cu || a.mask[(size_t)b * SM + k] != 0)) ? 0.f : -INFINITY;
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
   const bool active = q0 < S;  // wave-uniform
@@ -265,12 +273,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int j = 0; j < 8; ++j)
       d += Half16<T>::to_f(df0[j]) * Half16<T>::to_f(of0[j]) + Half16<T>::to_f(df1[j]) * Half16<T>::to_f(of1[j]);
     d = quad_sum(d);
-    if (active && g == 0 && q < S) a.delta[(size_t)bh * S + q] = d;
+    if (active && g == 0 && q < S) a.delta[(size_t)bh * SM + q] = d;
     ndelta = -d;
   }
   const float k2 = a.scale * LOG2E;
   // exp2(score2 + mask - lse2q) = p * scale; rows >= S get lse = +inf, i.e. p = 0 and a zero dQ row
-  const float lse2q = (q < S ? a.lse[(size_t)bh * S + qc] * LOG2E : INFINITY) - __log2f(a.scale);
+  const float lse2q = (q < S ? a.lse[(size_t)bh * SM + qc] * LOG2E : INFINITY) - __log2f(a.scale);
   const uint32_t rseed = attn_row_seed(drop_key(a.rng), drop_sample(a.rng, b) * a.A + h, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   const bool drop = a.drop_thr != 0;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     }
   }
   if (active && q < S) {
-    T* out = (T*)a.dqkv + ((size_t)b * S + q) * ld + h * HD;
+    T* out = (T*)a.dqkv + ((size_t)row0 + q) * ld + h * HD;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       short4v pk;
@@ -339,12 +347,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
-  const int S = a.S, ld = 3 * a.H;
-  const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
-  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
+  const int SM = a.S, ld = 3 * a.H;                    // SM: longest sequence (lse / delta stride)
+  const int row0 = a.cu ? a.cu[b] : b * SM;            // first token row of this sample
+  const int S = a.cu ? a.cu[b + 1] - row0 : SM;        // its length
+  const T* base = (const T*)a.qkv + (size_t)row0 * ld + h * HD;
+  const T* dob = (const T*)a.dctx + (size_t)row0 * a.H + h * HD;
   const int nqb = (S + 31) >> 5;  // 32-row query blocks
   const DropKey dk = drop_key(a.rng);
-  const int kvl = min(a.kv_len[b], S);
+  const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int k0 = blockIdx.y * ATT_ROWS + wave * 16;
   // keys at or beyond kv_len receive exactly zero gradient: such a workgroup / wave only writes zeros
   const bool blk_active = blockIdx.y * ATT_ROWS < kvl;  // workgroup-uniform
@@ -357,13 +367,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
   if (blk_active) {
     for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
       // log2-domain lse, +inf for the padding rows (p = 0); delta pre-multiplied by -scale
-      lse_s[i] = i < S ? a.lse[(size_t)bh * S + i] * LOG2E : INFINITY;
-      del_s[i] = i < S ? -a.scale * a.delta[(size_t)bh * S + i] : 0.f;
+      lse_s[i] = i < S ? a.lse[(size_t)bh * SM + i] * LOG2E : INFINITY;
+      del_s[i] = i < S ? -a.scale * a.delta[(size_t)bh * SM + i] : 0.f;
       seed_s[i] = attn_row_seed(dk, drop_sample(a.rng, b) * a.A + h, i);
     }
     const short8 kf0 = gfrag<T>(base + a.H, kc, ld, 0, lane), kf1 = gfrag<T>(base + a.H, kc, ld, 1, lane);
     const short8 vf0 = gfrag<T>(base + 2 * a.H, kc, ld, 0, lane), vf1 = gfrag<T>(base + 2 * a.H, kc, ld, 1, lane);
-    const float mb = (key < S && a.mask[(size_t)b * S + kc] != 0) ? 0.f : -INFINITY;
+    const float mb = (key < S && (a.cu || a.mask[(size_t)b * SM + kc] != 0)) ? 0.f : -INFINITY;
     const uint32_t kmul = (uint32_t)key * ATT_GOLD, thr_hi = attn_thr_hi(a.drop_thr);
     const float k2 = a.scale * LOG2E, dsc2 = a.drop_scale * a.scale;
     const bool drop = a.drop_thr != 0;
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
   }
   if (key < S) {
-    T* outk = (T*)a.dqkv + ((size_t)b * S + key) * ld + a.H + h * HD;
+    T* outk = (T*)a.dqkv + ((size_t)row0 + key) * ld + a.H + h * HD;
     T* outv = outk + a.H;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -471,17 +481,19 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
-  const int S = a.S, ld = 3 * a.H;
+  const int SM = a.S, ld = 3 * a.H;                    // SM: longest sequence (lse / delta stride)
+  const int row0 = a.cu ? a.cu[b] : b * SM;            // first token row of this sample
+  const int S = a.cu ? a.cu[b + 1] - row0 : SM;        // its length
 #ifdef PDT_ATT_STAMP  // phase time stamps of wave 0 (100 MHz counter) into the otherwise unused delta buffer
-#define PDT_STAMP(i) do { if (tid == 0) a.delta[(size_t)bh * S + (i)] = (float)(wall_clock64() & 0xFFFFFF); } while (0)
+#define PDT_STAMP(i) do { if (tid == 0) a.delta[(size_t)bh * SM + (i)] = (float)(wall_clock64() & 0xFFFFFF); } while (0)
 #else
 #define PDT_STAMP(i) do { } while (0)
 #endif
   PDT_STAMP(0);
-  const T* base = (const T*)a.qkv + (size_t)b * S * ld + h * HD;
-  const T* dob = (const T*)a.dctx + (size_t)b * S * a.H + h * HD;
-  const T* ob = (const T*)a.octx + (size_t)b * S * a.H + h * HD;
-  const int kvl = min(a.kv_len[b], S);
+  const T* base = (const T*)a.qkv + (size_t)row0 * ld + h * HD;
+  const T* dob = (const T*)a.dctx + (size_t)row0 * a.H + h * HD;
+  const T* ob = (const T*)a.octx + (size_t)row0 * a.H + h * HD;
+  const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int npb = (kvl + 31) >> 5, nqb = (S + 31) >> 5;
   const DropKey dk = drop_key(a.rng);
   const uint32_t thr_hi = attn_thr_hi(a.drop_thr);
@@ -504,8 +516,8 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
     int mask_raw = 0;
     float lse_raw = 0.f;
     if (tid < S) {
-      mask_raw = a.mask[(size_t)b * S + tid];
-      lse_raw = a.lse[(size_t)bh * S + tid];
+      mask_raw = a.cu ? 1 : a.mask[(size_t)b * SM + tid];
+      lse_raw = a.lse[(size_t)bh * SM + tid];
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -586,7 +598,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   if (r0 < S) {
     const int q = r0 + lm;
     if (q < S) {
-      T* out = (T*)a.dqkv + ((size_t)b * S + q) * ld + h * HD;
+      T* out = (T*)a.dqkv + ((size_t)row0 + q) * ld + h * HD;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         short4v pk;
@@ -664,7 +676,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
     }
   }
   if (key < S) {
-    T* outk = (T*)a.dqkv + ((size_t)b * S + key) * ld + a.H + h * HD;
+    T* outk = (T*)a.dqkv + ((size_t)row0 + key) * ld + a.H + h * HD;
     T* outv = outk + a.H;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -726,12 +738,13 @@ using namespace pdt;
 
 static int check_attn(int B, int S, int A) { return (B <= 0 || S <= 0 || S > ATT_SMAX || A <= 0) ? -3 : 0; }
 
-extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, void* ctx,
-                            float* lse, int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng,
+extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu,
+                            void* ctx, float* lse, int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng,
                             void* stream) {
   if (int e = check_attn(B, S, A)) return e;
+  if (!cu && (!mask || !kv_len)) return -3;
   AttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.ctx = ctx; a.lse = lse;
+  a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.cu = cu; a.ctx = ctx; a.lse = lse;
   a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = 0.125f;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
   return dtype == PDT_F16 ? attn_dispatch<_Float16>(0, a, (hipStream_t)stream) : attn_dispatch<__bf16>(0, a, (hipStream_t)stream);
@@ -753,13 +766,14 @@ static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) 
 
 extern "C" int pdt_attn_bwd_fuses_dbias(int S) { return S <= 128 ? 1 : 0; }
 
-extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const void* ctx,
-                            const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias, int B, int S,
-                            int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
+extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu,
+                            const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias,
+                            int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream) {
   if (int e = check_attn(B, S, A)) return e;
   if (dbias && !pdt_attn_bwd_fuses_dbias(S)) return -3;
+  if (!cu && (!mask || !kv_len)) return -3;
   AttnArgs a{};
-  a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.octx = ctx; a.dctx = dctx; a.lse = const_cast<float*>(lse);
+  a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.cu = cu; a.octx = ctx; a.dctx = dctx; a.lse = const_cast<float*>(lse);
   a.delta = delta; a.dqkv = dqkv;
   a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = 0.125f;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;

@@ -134,6 +134,7 @@ __device__ __forceinline__ DropKey drop_key(const RngArgs& r) {
 // Row of a [B*seq, H] activation -> the row its dropout counters are derived from (see PdtRng::sample_ids):
 // global sample id * 512 + position inside the sample (512 = the longest sequence the position table allows).
 __device__ __forceinline__ uint32_t drop_row(const RngArgs& r, uint32_t row) {
+  if (r.row_table) return r.row_table[row];
   if (!r.sample_ids) return row;
   const uint32_t b = __umulhi(row, r.seq_magic);
   return (uint32_t)r.sample_ids[b] * 512u + (row - b * r.seq);

@@ -230,8 +230,8 @@ struct GemmKernel {
     // sample-keyed dropout (PdtRng::sample_ids): when the sequence length is a multiple of 32 the 32 rows of a staged
     // block pair belong to ONE sample, so the id lookup is wave-uniform (a scalar load) and a row's dropout row is
     // m + offset; other lengths look the id up per row
-    const bool keyed = epi == EPI_BIAS_DROP_RES && g.drop_thr != 0 && g.rng.sample_ids != nullptr;
-    const bool keyed_uniform = keyed && (g.rng.seq & 31u) == 0;
+    const bool keyed = epi == EPI_BIAS_DROP_RES && g.drop_thr != 0 && (g.rng.sample_ids != nullptr || g.rng.row_table != nullptr);
+    const bool keyed_uniform = keyed && g.rng.row_table == nullptr && (g.rng.seq & 31u) == 0;
     auto fetch = [&](int ip, short8(&dst)[4]) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {

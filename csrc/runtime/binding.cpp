@@ -118,8 +118,9 @@ float keep_scale(double p) { return p <= 0.0 ? 1.0f : (float)(1.0 / (1.0 - p)); 
 using OptTensor = c10::optional<Tensor>;
 // `sids` (optional int32 [B] on the GPU): global sample ids - the dropout counters of row r of a [B*seq, H]
 // activation then derive from (sids[r / seq], r % seq), see PdtRng in api.h.
+// `rowmap` (optional int32 [T] on the GPU): unpadded activations - the dropout row of every packed row (PdtRng::row_table).
 PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site, const OptTensor& sids = c10::nullopt, int64_t seq = 1,
-                int64_t batch = -1) {
+                int64_t batch = -1, const OptTensor& rowmap = c10::nullopt) {
   TORCH_CHECK(state.is_cuda() && state.scalar_type() == at::kLong && state.numel() >= 2, "rng state: int64[2] on GPU");
   PdtRng r{reinterpret_cast<const uint64_t*>(state.data_ptr<int64_t>()), (uint32_t)micro, (uint32_t)site, nullptr, 1u, 0u};
   if (sids.has_value()) {
@@ -131,6 +132,11 @@ PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site, const OptTenso
     r.sample_ids = sids->data_ptr<int32_t>();
     r.seq = (uint32_t)seq;
     r.seq_magic = seq == 1 ? 0u : (uint32_t)(((uint64_t(1) << 32) + (uint64_t)seq - 1) / (uint64_t)seq);
+  }
+  if (rowmap.has_value()) {
+    TORCH_CHECK(rowmap->is_cuda() && rowmap->scalar_type() == at::kInt && rowmap->is_contiguous() && rowmap->dim() == 1,
+                "rowmap must be a contiguous int32 [T] GPU tensor");
+    r.row_table = reinterpret_cast<const uint32_t*>(rowmap->data_ptr<int32_t>());
   }
   return r;
 }
@@ -277,12 +283,22 @@ struct LayerDims { int B, S, A; double p_attn, p_hidden, eps; int64_t micro, lay
 std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Tensor& kv_len,
                                   const std::vector<Tensor>& w, const Tensor& rng_state, int64_t B, int64_t S, int64_t A,
                                   double p_attn, double p_hidden, double eps, int64_t micro, int64_t layer,
-                                  const OptTensor& sids) {
+                                  const OptTensor& sids, const OptTensor& cu, const OptTensor& rowmap) {
   DeviceGuard guard(x.device());
   chk16(x, "x");
   TORCH_CHECK(w.size() == 12, "layer_forward: 12 weight tensors expected");
   const int T = (int)x.size(0), H = (int)x.size(1);
-  TORCH_CHECK(T == B * S && H == A * 64, "layer_forward: head_dim must be 64 and x must be [B*S, H]");
+  // unpadded batch: x is the packed [T, H] of B samples whose first rows are cu[0..B) (cu[B] = T), S the longest one
+  const int32_t* cup = nullptr;
+  if (cu.has_value()) {
+    TORCH_CHECK(cu->is_cuda() && cu->scalar_type() == at::kInt && cu->is_contiguous() && cu->numel() == B + 1,
+                "cu_seqlens must be a contiguous int32 [B+1] GPU tensor");
+    TORCH_CHECK(rowmap.has_value() && rowmap->numel() == T, "an unpadded batch needs the per-row dropout table");
+    TORCH_CHECK(T <= B * S && H == A * 64, "layer_forward: packed x has more rows than B * S");
+    cup = cu->data_ptr<int32_t>();
+  } else {
+    TORCH_CHECK(T == B * S && H == A * 64, "layer_forward: head_dim must be 64 and x must be [B*S, H]");
+  }
   auto f32 = x.options().dtype(at::kFloat);
   const int64_t site = layer * 4;
 
@@ -291,12 +307,12 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
 
   Tensor ctx = at::empty({T, H}, x.options());
   Tensor lse = at::empty({B, A, S}, f32);
-  check(pdt_attn_fwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+  check(pdt_attn_fwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), cup, ctx.data_ptr(),
                      lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p_attn), thr16(p_attn),
                      make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()), "attn_fwd");
 
   Epi e_ao; e_ao.kind = PDT_EPI_BIAS_DROP_RES; e_ao.bias = &w[3]; e_ao.res = &x; e_ao.drop_p = p_hidden;
-  e_ao.rng = make_rng(rng_state, micro, site + 1, sids, S, B);
+  e_ao.rng = make_rng(rng_state, micro, site + 1, sids, S, B, rowmap);
   Tensor z1 = gemm_nt(ctx, w[2], e_ao);
   Tensor stats1 = at::empty({T, 2}, f32);
   Tensor x1 = ln_fwd(z1, w[4], w[5], stats1, eps);
@@ -306,7 +322,7 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
   Tensor gact = gemm_nt(x1, w[6], e_f1);
 
   Epi e_f2; e_f2.kind = PDT_EPI_BIAS_DROP_RES; e_f2.bias = &w[9]; e_f2.res = &x1; e_f2.drop_p = p_hidden;
-  e_f2.rng = make_rng(rng_state, micro, site + 2, sids, S, B);
+  e_f2.rng = make_rng(rng_state, micro, site + 2, sids, S, B, rowmap);
   Tensor z2 = gemm_nt(gact, w[8], e_f2);
   Tensor stats2 = at::empty({T, 2}, f32);
   Tensor x2 = ln_fwd(z2, w[10], w[11], stats2, eps);
@@ -316,8 +332,10 @@ std::vector<Tensor> layer_forward(const Tensor& x, const Tensor& mask, const Ten
 Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Tensor>& sv, const Tensor& mask,
                       const Tensor& kv_len, const std::vector<Tensor>& w, std::vector<Tensor> gr,
                       const Tensor& rng_state, int64_t B, int64_t S, int64_t A, double p_attn, double p_hidden,
-                      int64_t micro, int64_t layer, bool accumulate, const OptTensor& sids) {
+                      int64_t micro, int64_t layer, bool accumulate, const OptTensor& sids, const OptTensor& cu,
+                      const OptTensor& rowmap) {
   DeviceGuard guard(x.device());
+  const int32_t* cup = cu.has_value() ? cu->data_ptr<int32_t>() : nullptr;
   TORCH_CHECK(sv.size() == 10 && w.size() == 12 && gr.size() == 12, "layer_backward: bad list sizes");
   const Tensor dy = dy_in.contiguous();
   chk16(dy, "dy");
@@ -327,7 +345,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   const int64_t site = layer * 4;
 
   // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
-  LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2, sids, S, B),
+  LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2, sids, S, B, rowmap),
                        accumulate);
   // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU) ; wgrad
   Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
@@ -340,7 +358,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   lane.run([&] { gemm_tn_into(du, x1, gr[6], accumulate); });
   Tensor dx1 = gemm_nn(du, w[6], e_add);
   // LN1
-  LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1, sids, S, B),
+  LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1, sids, S, B, rowmap),
                        accumulate);
   // attention output projection
   lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); });
@@ -351,7 +369,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // the short-sequence backward kernel also emits per-sample column sums of dqkv (the QKV bias gradient)
   const bool fused_db = pdt_attn_bwd_fuses_dbias((int)S) != 0;
   Tensor db_part = fused_db ? at::empty({B, 3 * (int64_t)H}, lse.options()) : Tensor();
-  check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+  check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), cup, ctx.data_ptr(),
                      dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
                      fused_db ? db_part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
                      thr16(p_attn), make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()),
@@ -376,11 +394,16 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
 std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor& pos_ids, const Tensor& type_ids,
                                   const c10::optional<Tensor>& inputs_embeds, const Tensor& word, const Tensor& pos,
                                   const Tensor& type, const Tensor& gamma, const Tensor& beta, const Tensor& rng_state,
-                                  double eps, double p, int64_t micro, int64_t site, const OptTensor& sids, int64_t seq) {
+                                  double eps, double p, int64_t micro, int64_t site, const OptTensor& sids, int64_t seq,
+                                  const OptTensor& rowmap) {
   DeviceGuard guard(word.device());
   const int H = (int)word.size(1);
   const int tokens = (int)pos_ids.numel();
-  TORCH_CHECK(seq >= 1 && tokens % seq == 0, "embed_forward: tokens must be a multiple of the sequence length");
+  TORCH_CHECK(rowmap.has_value() || (seq >= 1 && tokens % seq == 0),
+              "embed_forward: tokens must be a multiple of the sequence length");
+  const OptTensor no_ids;
+  const OptTensor& rsids = rowmap.has_value() ? no_ids : sids;  // (packed rows: the table alone defines the dropout rows)
+  const int64_t rbatch = rowmap.has_value() ? -1 : tokens / seq;
   Tensor pre = at::empty({tokens, H}, word.options());
   Tensor y = at::empty({tokens, H}, word.options());
   Tensor stats = at::empty({tokens, 2}, word.options().dtype(at::kFloat));
@@ -391,7 +414,7 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
                       word.data_ptr(), pos.data_ptr(), type.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                       pre.data_ptr(), y.data_ptr(), stats.data_ptr<float>(), tokens, H, (int)word.size(0), (int)pos.size(0),
                       (int)type.size(0), (float)eps, keep_scale(p),
-                      thr16(p), make_rng(rng_state, micro, site, sids, seq, tokens / seq), cur_stream()), "embed_fwd");
+                      thr16(p), make_rng(rng_state, micro, site, rsids, seq, rbatch, rowmap), cur_stream()), "embed_fwd");
   return {y, pre, stats};
 }
 
@@ -400,8 +423,10 @@ std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor
 Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stats, const c10::optional<Tensor>& ids,
                       const Tensor& pos_ids, const Tensor& type_ids, const Tensor& gamma, std::vector<Tensor> gr,
                       const Tensor& rng_state, double p, int64_t micro, int64_t site, int64_t pad_id, bool accumulate,
-                      const OptTensor& sids, int64_t seq) {
+                      const OptTensor& sids, int64_t seq, const OptTensor& rowmap) {
   DeviceGuard guard(pre.device());
+  const OptTensor no_ids;
+  const OptTensor& rsids = rowmap.has_value() ? no_ids : sids;
   TORCH_CHECK(gr.size() == 5, "embed_backward: 5 gradient tensors expected");
   const Tensor dy = dy_in.contiguous();
   const int tokens = (int)pre.size(0), H = (int)pre.size(1);
@@ -409,7 +434,8 @@ Tensor embed_backward(const Tensor& dy_in, const Tensor& pre, const Tensor& stat
   if (p > 0.0) {
     dmask = at::empty_like(dy);
     check(pdt_dropout_apply(dt_code(dy), dy.data_ptr(), dmask.data_ptr(), dy.numel(), H, keep_scale(p), thr16(p),
-                            make_rng(rng_state, micro, site, sids, seq, tokens / seq), cur_stream()), "dropout_apply");
+                            make_rng(rng_state, micro, site, rsids, seq, rowmap.has_value() ? -1 : tokens / seq, rowmap),
+                            cur_stream()), "dropout_apply");
   }
   LnBwdOut l = ln_bwd(dmask, pre, stats, gamma, &gr[3], &gr[4], nullptr, 0.0, make_rng(rng_state, micro, site),
                       accumulate);
@@ -592,21 +618,23 @@ std::vector<Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& x, const Te
 }
 std::vector<Tensor> op_attn_fwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, int64_t B, int64_t S, int64_t A,
                                 const c10::optional<Tensor>& rng_state, double p, int64_t micro, int64_t site,
-                                const OptTensor& sids) {
+                                const OptTensor& sids, const OptTensor& cu) {
   DeviceGuard guard(qkv.device());
   chk16(qkv, "qkv");
-  TORCH_CHECK(qkv.is_contiguous() && qkv.size(0) == B * S && qkv.size(1) == 3 * A * 64, "qkv must be [B*S, 3*A*64]");
-  Tensor ctx = at::empty({B * S, A * 64}, qkv.options());
+  TORCH_CHECK(qkv.is_contiguous() && (cu.has_value() || qkv.size(0) == B * S) && qkv.size(1) == 3 * A * 64,
+              "qkv must be [B*S, 3*A*64]");
+  Tensor ctx = at::empty({qkv.size(0), A * 64}, qkv.options());
   Tensor lse = at::empty({B, A, S}, qkv.options().dtype(at::kFloat));
   PdtRng rng{nullptr, 0, 0};
   if (rng_state.has_value()) rng = make_rng(*rng_state, micro, site, sids, S, B);
-  check(pdt_attn_fwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+  check(pdt_attn_fwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(),
+                     cu.has_value() ? cu->data_ptr<int32_t>() : nullptr, ctx.data_ptr(),
                      lse.data_ptr<float>(), (int)B, (int)S, (int)A, keep_scale(p), thr16(p), rng, cur_stream()), "attn_fwd");
   return {ctx, lse};
 }
 Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, const Tensor& ctx, const Tensor& dctx,
                    const Tensor& lse, int64_t B, int64_t S, int64_t A, const c10::optional<Tensor>& rng_state, double p,
-                   int64_t micro, int64_t site, c10::optional<Tensor> dbias, const OptTensor& sids) {
+                   int64_t micro, int64_t site, c10::optional<Tensor> dbias, const OptTensor& sids, const OptTensor& cu) {
   DeviceGuard guard(qkv.device());
   Tensor dqkv = at::empty_like(qkv);
   Tensor delta = at::empty_like(lse);
@@ -617,7 +645,8 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
   const int64_t H3 = qkv.size(1);
   Tensor part;
   if (dbias.has_value()) { chkf32(*dbias, "dbias"); part = at::empty({B, H3}, lse.options()); }
-  check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), ctx.data_ptr(),
+  check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(),
+                     cu.has_value() ? cu->data_ptr<int32_t>() : nullptr, ctx.data_ptr(),
                      dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
                      dbias.has_value() ? part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p),
                      thr16(p), rng, cur_stream()), "attn_bwd");
@@ -667,10 +696,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("rng_state"), py::arg("drop_p"), py::arg("micro"), py::arg("site"), py::arg("sample_ids") = py::none(),
         py::arg("seq") = 1);
   m.def("op_attn_fwd", &op_attn_fwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("B"), py::arg("S"), py::arg("A"),
-        py::arg("rng_state"), py::arg("p"), py::arg("micro"), py::arg("site"), py::arg("sample_ids") = py::none());
+        py::arg("rng_state"), py::arg("p"), py::arg("micro"), py::arg("site"), py::arg("sample_ids") = py::none(),
+        py::arg("cu_seqlens") = py::none());
   m.def("op_attn_bwd", &op_attn_bwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("ctx"), py::arg("dctx"),
         py::arg("lse"), py::arg("B"), py::arg("S"), py::arg("A"), py::arg("rng_state"), py::arg("p"), py::arg("micro"),
-        py::arg("site"), py::arg("dbias") = py::none(), py::arg("sample_ids") = py::none());
+        py::arg("site"), py::arg("dbias") = py::none(), py::arg("sample_ids") = py::none(), py::arg("cu_seqlens") = py::none());
   m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
         "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
   m.def("set_gemm_persistent", [](int64_t mode) { pdt_gemm_set_persist_mode((int)mode); },

@@ -61,9 +61,13 @@ class MaskInfo:
     so it can skip key blocks that are entirely padding.
     """
 
-    def __init__(self, mask: Optional[torch.Tensor], batch: int, seq: int, device):
+    def __init__(self, mask: Optional[torch.Tensor], batch: int, seq: int, device, cu_seqlens=None, rowmap=None):
+        """`cu_seqlens` / `rowmap`: an UNPADDED batch (native path only) - the hidden states are the packed [T, H] rows
+        of the real tokens, sample b owns rows cu_seqlens[b] .. cu_seqlens[b+1], `seq` is the longest sample and
+        `rowmap[t]` the dropout row (sample id * 512 + position) of packed row t."""
         self.batch, self.seq = batch, seq
-        if mask is None:
+        self.cu, self.rowmap = cu_seqlens, rowmap
+        if mask is None and cu_seqlens is None:
             mask = torch.ones(batch, seq, dtype=torch.int32, device=device)
         self.mask = mask
         self._ext = {}
@@ -75,6 +79,9 @@ class MaskInfo:
         return self._ext[dtype]
 
     def native(self):
+        if self._native is None and self.cu is not None:
+            dummy = torch.zeros(1, dtype=torch.int32, device=self.cu.device)  # (never read: every key of a sample is real)
+            self._native = (dummy, dummy)
         if self._native is None:
             m = self.mask.to(torch.int32).contiguous()
             idx = torch.arange(1, self.seq + 1, device=m.device, dtype=torch.int32)
@@ -360,6 +367,40 @@ class _ClassifierBase(nn.Module):
         if self.runtime is not None:
             self.runtime.begin_forward(sample_ids, train=self.training and torch.is_grad_enabled())
 
+    # -- unpadded ("varlen") execution of the native path ----------------------------------------------------------
+    def _can_run_unpadded(self, input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
+        return (cu_seqlens is not None and token_index is not None and self.runtime is not None and input_ids is not None
+                and input_ids.is_cuda and inputs_embeds is None and hidden_states is None and not output_hidden_states
+                and getattr(self, "with_head", False) and self.base_model.embeddings is not None)
+
+    def _forward_unpadded(self, input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index):
+        """The whole model on the T real tokens of a dynamically padded batch (T = cu_seqlens[-1]): embeddings, every
+        GEMM, LayerNorm and attention work on packed [T, H] rows; the pooler reads the first row of every sample.
+        Numerically the padded computation restricted to the real tokens (padding never influences them); dropout
+        masks are keyed by (sample, position), so they are those of the padded run too.  ``last_hidden_state`` of
+        the result is the packed [T, H] tensor."""
+        from ..ops import fused
+
+        B, S = input_ids.shape
+        base = self.base_model
+        emb = base.embeddings
+        tok = token_index
+        ids = input_ids.reshape(-1)[tok]
+        types = (token_type_ids.reshape(-1)[tok] if token_type_ids is not None else torch.zeros_like(ids))
+        pos = emb.position_ids(input_ids, B, S, input_ids.device).reshape(-1)[tok]
+        b_of = torch.div(tok, S, rounding_mode="floor")
+        sid = sample_ids.reshape(-1).to(torch.int64)[b_of] if sample_ids is not None else b_of
+        rowmap = (sid * 512 + (tok - b_of * S)).to(torch.int32)
+        cu = cu_seqlens.to(torch.int32)
+        mask = MaskInfo(None, B, S, input_ids.device, cu_seqlens=cu, rowmap=rowmap)
+        x = fused.embeddings_forward_packed(emb, ids, types, pos, rowmap)
+        for lyr in base.encoder.layers():
+            x = fused.encoder_layer_forward(lyr, x, mask)
+        first = x.index_select(0, cu[:-1].to(torch.int64)).unsqueeze(1)  # token 0 of every sample: [B, 1, H]
+        res = self.head(first, labels)
+        res.last_hidden_state = x
+        return res
+
     @property
     def base_model(self) -> BertModel:
         return getattr(self, self.base_model_prefix)
@@ -435,8 +476,10 @@ class BertForSequenceClassification(_ClassifierBase):
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
-                sample_ids=None, **unused):
+                sample_ids=None, cu_seqlens=None, token_index=None, **unused):
         self._begin_forward(sample_ids)
+        if self._can_run_unpadded(input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
+            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index)
         out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack
@@ -495,8 +538,10 @@ class RobertaForSequenceClassification(_ClassifierBase):
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None,
                 inputs_embeds=None, output_hidden_states=False, return_dict=True, rng=None, hidden_states=None,
-                sample_ids=None, **unused):
+                sample_ids=None, cu_seqlens=None, token_index=None, **unused):
         self._begin_forward(sample_ids)
+        if self._can_run_unpadded(input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
+            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index)
         out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack

@@ -125,40 +125,43 @@ class _LayerFn(torch.autograd.Function):
     def forward(ctx, x, layer, mask):
         nat: LayerNative = layer._native
         cfg = layer.cfg
-        B, S, H = x.shape
+        packed = mask.cu is not None  # unpadded batch: x is [T, H], sample b = rows cu[b] .. cu[b+1]
+        B, S, H = (mask.batch, mask.seq, x.shape[-1]) if packed else x.shape
         m, kvl = mask.native()
         train = layer.training
         key = nat.rt.key
-        x2 = x.reshape(B * S, H)
+        x2 = x if packed else x.reshape(B * S, H)
         outs = native().layer_forward(
             x2, m, kvl, nat.w, key.state, B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            cfg.layer_norm_eps, key.counter, layer.index + nat.site_offset, key.sample_ids)
-        ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl), x2, outs[1:]
-        ctx.meta = (B, S, H, train, key)
-        return outs[0].view(B, S, H)
+            cfg.layer_norm_eps, key.counter, layer.index + nat.site_offset, key.sample_ids, mask.cu, mask.rowmap)
+        ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl, mask.cu, mask.rowmap), x2, outs[1:]
+        ctx.meta = (B, S, H, train, key, packed)
+        return outs[0] if packed else outs[0].view(B, S, H)
 
     @staticmethod
     def backward(ctx, dy):
         layer = ctx.layer
         nat: LayerNative = layer._native
         cfg = layer.cfg
-        B, S, H, train, key = ctx.meta
+        B, S, H, train, key, packed = ctx.meta
         acc = nat.arena.take_accumulate_flag(nat.segment)
         dx = native().layer_backward(
-            dy.reshape(B * S, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, key.state,
+            dy.reshape(-1, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, key.state,
             B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
-            key.counter, layer.index + nat.site_offset, acc, key.sample_ids)
+            key.counter, layer.index + nat.site_offset, acc, key.sample_ids, ctx.mask[2], ctx.mask[3])
         ctx.saved = ctx.x2 = None
         nat.rt.done(nat.segment)
-        return dx.view(B, S, H), None, None
+        return (dx if packed else dx.view(B, S, H)), None, None
 
 
 def encoder_layer_forward(layer, hidden, mask, rng=None):
     nat = layer._native
     if hidden.dtype != nat.w[0].dtype:
         hidden = hidden.to(nat.w[0].dtype)
+    if hidden.dim() == 2 and mask.cu is None:
+        raise ValueError("2-D hidden states are the packed rows of an unpadded batch: the mask must carry cu_seqlens")
     if not hidden.requires_grad and torch.is_grad_enabled():
         # the stack must stay on the tape even when its input is a constant (e.g. a pipeline stage whose
         # input arrived from the previous rank): parameter gradients are produced inside backward()
@@ -183,10 +186,11 @@ class EmbedNative:
 
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, emb, ids, type_ids, pos_ids, inputs_embeds):
+    def forward(ctx, anchor, emb, ids, type_ids, pos_ids, inputs_embeds, rowmap):
         nat: EmbedNative = emb._native
         cfg = emb.cfg
-        B, S = pos_ids.shape
+        # (packed rows of an unpadded batch: pos_ids is [T]; the row table alone defines the dropout rows)
+        B, S = pos_ids.shape if rowmap is None else (1, pos_ids.numel())
         train = emb.training
         key = nat.rt.key
         idf = ids.reshape(-1).contiguous() if ids is not None else None
@@ -194,26 +198,26 @@ class _EmbedFn(torch.autograd.Function):
         pf, tf = pos_ids.reshape(-1).contiguous(), type_ids.reshape(-1).contiguous()
         y, pre, stats = native().embed_forward(idf, pf, tf, ie, *nat.w, key.state, cfg.layer_norm_eps,
                                                cfg.hidden_dropout_prob if train else 0.0, key.counter,
-                                               SITE_EMBED + nat.site_offset, key.sample_ids, S)
+                                               SITE_EMBED + nat.site_offset, key.sample_ids, S, rowmap)
         ctx.emb, ctx.idx, ctx.saved = emb, (idf, pf, tf), (pre, stats)
-        ctx.meta = (B, S, train, key, ie is not None)
-        return y.view(B, S, cfg.hidden_size)
+        ctx.meta = (B, S, train, key, ie is not None, rowmap)
+        return y if rowmap is not None else y.view(B, S, cfg.hidden_size)
 
     @staticmethod
     def backward(ctx, dy):
         emb = ctx.emb
         nat: EmbedNative = emb._native
         cfg = emb.cfg
-        B, S, train, key, has_ie = ctx.meta
+        B, S, train, key, has_ie, rowmap = ctx.meta
         idf, pf, tf = ctx.idx
         pre, stats = ctx.saved
         acc = nat.arena.take_accumulate_flag(nat.segment)
         dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.g,
                                        key.state, cfg.hidden_dropout_prob if train else 0.0, key.counter,
-                                       SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc, key.sample_ids, S)
+                                       SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc, key.sample_ids, S, rowmap)
         ctx.saved = None
         nat.rt.done(nat.segment)
-        return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None)
+        return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None), None
 
 
 def embeddings_forward(emb, input_ids, token_type_ids, pos_ids, inputs_embeds, rng=None):
@@ -223,7 +227,12 @@ def embeddings_forward(emb, input_ids, token_type_ids, pos_ids, inputs_embeds, r
     # `anchor` ties the node to the tape: its gradient is never materialised (grads go to the arena)
     anchor = emb.LayerNorm.weight
     return _EmbedFn.apply(anchor, emb, None if inputs_embeds is not None else input_ids, token_type_ids, pos_ids,
-                          inputs_embeds)
+                          inputs_embeds, None)
+
+
+def embeddings_forward_packed(emb, ids, type_ids, pos_ids, rowmap):
+    """Embeddings of the T real tokens of an unpadded batch (all arguments [T]); returns the packed [T, H] rows."""
+    return _EmbedFn.apply(emb.LayerNorm.weight, emb, ids, type_ids, pos_ids, None, rowmap)
 
 
 # --------------------------------------------------------------------------------------------------

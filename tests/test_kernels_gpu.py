@@ -356,7 +356,7 @@ def test_embeddings_fwd_bwd(dtype):
     pids = torch.arange(S, device="cuda").repeat(B)
     tids = torch.randint(0, R, (B * S,), device="cuda")
     st = rng_state()
-    y, pre, stats = C().embed_forward(ids, pids, tids, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
+    y, pre, stats = C().embed_forward(ids, pids, tids, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1, None)
     wf, pf, tf = word.float().requires_grad_(), pos.float().requires_grad_(), typ.float().requires_grad_()
     gf, bf = g.float().requires_grad_(), b.float().requires_grad_()
     e = F.embedding(ids, wf, padding_idx=0) + F.embedding(pids, pf) + F.embedding(tids, tf)
@@ -367,7 +367,7 @@ def test_embeddings_fwd_bwd(dtype):
     f32 = dict(device="cuda", dtype=torch.float32)
     grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
              torch.zeros(H, **f32)]
-    C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, False, None, 1)
+    C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, False, None, 1, None)
     for got, want in zip(grads, [wf.grad, pf.grad, tf.grad, gf.grad, bf.grad]):
         assert rel_err(got, want) < 2e-2
     assert grads[0][0].abs().max().item() == 0  # padding row
@@ -397,7 +397,7 @@ def test_embedding_table_gradients_are_a_deterministic_segmented_sum():
     f32 = dict(device="cuda", dtype=torch.float32)
 
     def run(grads, acc):
-        return C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, acc, None, 1)
+        return C().embed_backward(dy, pre, stats, ids, pids, tids, g, grads, st, 0.0, 0, 0, 0, acc, None, 1, None)
 
     mk = lambda: [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
                   torch.zeros(H, **f32)]
@@ -650,16 +650,50 @@ def test_embedding_indices_outside_their_tables_are_clamped_not_dereferenced():
     bad_ids, bad_p, bad_t = ids.clone(), pids.clone(), tids.clone()
     bad_ids[3], bad_ids[10], bad_p[5], bad_t[7], bad_t[8] = V + 5, -4, P + 100, 28995, -1
     st = rng_state()
-    y_bad, pre_bad, stats_bad = C().embed_forward(bad_ids, bad_p, bad_t, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
+    y_bad, pre_bad, stats_bad = C().embed_forward(bad_ids, bad_p, bad_t, None, word, pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1, None)
     y_ref, _, _ = C().embed_forward(bad_ids.clamp(0, V - 1), bad_p.clamp(0, P - 1), bad_t.clamp(0, R - 1), None, word,
-                                    pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1)
+                                    pos, typ, g, b, st, 1e-12, 0.0, 0, 0, None, 1, None)
     assert torch.equal(y_bad, y_ref)
     f32 = dict(device="cuda", dtype=torch.float32)
     grads = [torch.zeros(V, H, **f32), torch.zeros(P, H, **f32), torch.zeros(R, H, **f32), torch.zeros(H, **f32),
              torch.zeros(H, **f32)]
     dy = torch.randn(T, H, device="cuda").to(dtype)
-    C().embed_backward(dy, pre_bad, stats_bad, bad_ids, bad_p, bad_t, g, grads, st, 0.0, 0, 0, 0, False, None, 1)
+    C().embed_backward(dy, pre_bad, stats_bad, bad_ids, bad_p, bad_t, g, grads, st, 0.0, 0, 0, 0, False, None, 1, None)
     torch.cuda.synchronize()
     assert all(torch.isfinite(x).all() for x in grads)
     # rows of valid tokens received their gradient; nothing was written for the out-of-table word / position rows
     assert grads[0][ids[0]].abs().sum() > 0 and grads[1][pids[0]].abs().sum() > 0
+
+
+@pytest.mark.parametrize("smax", [96, 320])
+def test_attention_unpadded_batch_equals_padded(smax):
+    """cu_seqlens: the samples' rows are packed back to back; forward output, dQ/dK/dV of the real tokens equal the
+    padded [B, S] run with key lengths (both the fused S <= 128 backward and the two-kernel path), dropout on."""
+    torch.manual_seed(5)
+    dtype = torch.float16
+    A, B = 4, 5
+    H = A * 64
+    lens = [smax, 17, smax // 2, 64, 33]
+    S = max(lens)
+    qkv_pad = torch.zeros(B, S, 3 * H, device="cuda", dtype=dtype)
+    dctx_pad = torch.zeros(B, S, H, device="cuda", dtype=dtype)
+    mask = torch.zeros(B, S, dtype=torch.int32, device="cuda")
+    for b, n in enumerate(lens):
+        qkv_pad[b, :n] = (torch.randn(n, 3 * H, device="cuda") * 0.7).to(dtype)
+        dctx_pad[b, :n] = torch.randn(n, H, device="cuda").to(dtype)
+        mask[b, :n] = 1
+    kv_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    rows = torch.cat([torch.arange(n) + b * S for b, n in enumerate(lens)]).cuda()
+    qkv = qkv_pad.reshape(B * S, -1)[rows].contiguous()
+    dctx = dctx_pad.reshape(B * S, -1)[rows].contiguous()
+    sids = torch.arange(70, 70 + B, dtype=torch.int32, device="cuda")
+    st = rng_state()
+    dummy = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx_p, lse_p = C().op_attn_fwd(qkv_pad.reshape(B * S, -1), mask, kv_len, B, S, A, st, 0.2, 3, 9, sids)
+    ctx_u, lse_u = C().op_attn_fwd(qkv, dummy, dummy, B, S, A, st, 0.2, 3, 9, sids, cu)
+    torch.testing.assert_close(ctx_u, ctx_p[rows], rtol=1e-3, atol=1e-3)
+    dq_p = C().op_attn_bwd(qkv_pad.reshape(B * S, -1), mask, kv_len, ctx_p, dctx_pad.reshape(B * S, -1), lse_p, B, S, A, st, 0.2, 3, 9,
+                           None, sids)
+    dq_u = C().op_attn_bwd(qkv, dummy, dummy, ctx_u, dctx, lse_u, B, S, A, st, 0.2, 3, 9, None, sids, cu)
+    assert rel_err(dq_u.float(), dq_p[rows].float()) < 2e-3

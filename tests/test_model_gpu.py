@@ -420,3 +420,48 @@ def test_overlapped_accumulation_window_equals_the_plain_loop():
     l1, g1, m1 = run(True)
     assert l0 == l1 and g0.abs().sum() > 0
     assert torch.equal(g0, g1) and torch.equal(m0, m1)
+
+
+@pytest.mark.parametrize("name", ["bert-tiny", "roberta-tiny"])
+def test_unpadded_execution_matches_the_padded_batch(name):
+    """`cu_seqlens` / `token_index` (PadCollator(varlen=True)): the encoder runs on the real tokens only.  Logits,
+    loss and every parameter gradient equal the padded run - with dropout ON, because the masks are keyed by
+    (sample, position) in both layouts."""
+    from pytorch_distributed_training_amd.data import PadCollator
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+
+    torch.manual_seed(0)
+    m = build_model(name).cuda()
+    arena = ParamArena(m, torch.device("cuda"), torch.float16)
+    m.enable_native(arena, seed=7, global_seed=5)
+    g = torch.Generator().manual_seed(2)
+    lens = [37, 12, 64, 5, 29, 48]
+    pad = m.config.pad_token_id
+    examples = [{"input_ids": torch.randint(5, 500, (n,), generator=g).tolist(), "attention_mask": [1] * n,
+                 "token_type_ids": ([0] * (n // 2) + [1] * (n - n // 2)) if name == "bert-tiny" else [0] * n,
+                 "labels": int(i % 2), "sample_ids": 40 + i} for i, n in enumerate(lens)]
+    batch = PadCollator(pad, varlen=True)(examples).to("cuda")
+    assert batch["cu_seqlens"].tolist() == [0, 37, 49, 113, 118, 147, 195] and batch["token_index"].numel() == 195
+    padded = {k: v for k, v in batch.items() if k not in ("cu_seqlens", "token_index")}
+    m.train()
+    arena.zero_grad()
+    out_p = m(**padded)
+    out_p.loss.backward()
+    g_p = arena.grad.clone()
+    arena.window -= 1
+    arena.zero_grad()
+    out_u = m(**batch)
+    assert out_u.last_hidden_state.shape == (195, m.config.hidden_size)
+    out_u.loss.backward()
+    torch.testing.assert_close(out_u.logits, out_p.logits, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(out_u.loss, out_p.loss, rtol=2e-3, atol=2e-3)
+    rel = ((arena.grad - g_p).norm() / g_p.norm()).item()
+    assert rel < 2e-2, rel
+    # rows of the packed output are the real-token rows of the padded output
+    tok = batch["token_index"]
+    torch.testing.assert_close(out_u.last_hidden_state, out_p.last_hidden_state.reshape(-1, m.config.hidden_size)[tok],
+                               rtol=2e-2, atol=2e-2)
+    m.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m(**batch).logits, m(**padded).logits, rtol=5e-3, atol=5e-3)
