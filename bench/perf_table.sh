@@ -13,6 +13,7 @@ run --batch 128
 run --dtype bf16
 run --dtype bf16 --seq-len 512
 run --batch 96 --accum 12
+PDT_OVERLAP_MICRO=0 run --batch 96 --accum 12
 run --batch 8
 run --model roberta-large --dtype bf16 --seq-len 512
 for b in 1024 256; do
