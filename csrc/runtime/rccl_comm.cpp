@@ -7,8 +7,10 @@
 
 #include "../kernels/api.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace py = pybind11;
 
@@ -208,6 +210,26 @@ void RcclComm::synchronize() {
   PDT_HIP(hipStreamSynchronize(stream_));
 }
 
+bool RcclComm::wait_idle(double seconds) {
+  TORCH_CHECK(comm_, "communicator is closed");
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+  for (;;) {
+    const hipError_t e = hipStreamQuery(stream_);
+    if (e == hipSuccess) return true;
+    TORCH_CHECK(e == hipErrorNotReady, "HIP error in RcclComm: ", hipGetErrorString(e), " (hipStreamQuery)");
+    ncclResult_t async = ncclSuccess;
+    if (ncclCommGetAsyncError(comm_, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) return false;
+    if (std::chrono::steady_clock::now() >= deadline) return false;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+void RcclComm::abort() {
+  if (!comm_) return;
+  (void)ncclCommAbort(comm_);
+  comm_ = nullptr;  // (stream and events are left to the process exit: work that was aborted may still refer to them)
+}
+
 int64_t RcclComm::comm_count() const {
   TORCH_CHECK(comm_, "communicator is closed");
   int n = 0;
@@ -249,6 +271,9 @@ void bind_rccl_comm(py::module_& m) {
       .def("p2p_async", &RcclComm::p2p_async, py::arg("kinds"), py::arg("tensors"), py::arg("peers"))
       .def("barrier", &RcclComm::barrier, py::call_guard<py::gil_scoped_release>())
       .def("synchronize", &RcclComm::synchronize, py::call_guard<py::gil_scoped_release>())
+      .def("wait_idle", &RcclComm::wait_idle, py::arg("seconds"), py::call_guard<py::gil_scoped_release>(),
+           "poll the communication stream until it has drained: False after `seconds`, or on an asynchronous RCCL error")
+      .def("abort", &RcclComm::abort, py::call_guard<py::gil_scoped_release>(), "ncclCommAbort: give up on a communicator whose work does not finish")
       .def("check_async_error", &RcclComm::check_async_error)
       .def("comm_count", &RcclComm::comm_count, "ranks of the communicator as RCCL itself reports them (ncclCommCount)")
       .def("close", &RcclComm::close, py::call_guard<py::gil_scoped_release>())

@@ -67,6 +67,10 @@ class RcclComm {
   // raises if RCCL has recorded an asynchronous error on this communicator (the watchdog's poll)
   void check_async_error();
   void synchronize();  // host wait for the communication stream
+  // bounded host wait: true once the communication stream has drained, false after `seconds` or on an asynchronous
+  // RCCL error (the start-up self test uses it so that a communicator that cannot make progress is abandoned, not waited for)
+  bool wait_idle(double seconds);
+  void abort();        // ncclCommAbort
   void close();        // orderly ncclCommDestroy; a communicator that was never closed is left to the process exit
   int64_t collectives() const { return launches_; }
   int64_t bytes() const { return bytes_; }

@@ -81,6 +81,7 @@ class DistributedShardSampler(Sampler):
         self.n = len(dataset)
         self.num_replicas, self.rank, self.shuffle, self.seed, self.drop_last = num_replicas, rank, shuffle, seed, drop_last
         self.epoch = 0
+        self.frozen = False  # True: set_epoch() is ignored - a script that never calls it sees the same order every epoch
         if drop_last and self.n % num_replicas:
             self.num_samples = math.ceil((self.n - num_replicas) / num_replicas)
         else:
@@ -88,7 +89,8 @@ class DistributedShardSampler(Sampler):
         self.total_size = self.num_samples * num_replicas
 
     def set_epoch(self, epoch: int) -> None:
-        self.epoch = epoch
+        if not self.frozen:
+            self.epoch = epoch
 
     def __len__(self) -> int:
         return self.num_samples

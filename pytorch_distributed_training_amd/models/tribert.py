@@ -255,7 +255,7 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     from ..models.config import preset
     from ..optim import AdamW, get_linear_schedule_with_warmup
     from ..parallel.groups import ParallelMesh
-    from ..recipes import _collator, build_datasets
+    from ..recipes import _collator, build_datasets, model_parallel_loaders
     from ..utils.logging import StepLogger
     from ..utils.seed import seed_step, set_seed
     from ..utils.watchdog import StepWatchdog, inject_fault
@@ -269,8 +269,7 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     train_ds, val_ds = build_datasets(cfg, model_cfg)
     accum, micro_bs = cfg.accumulation()
     collate = _collator(cfg, model_cfg)
-    train_dl = DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=micro_bs)
-    eval_dl = DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size)
+    train_dl, eval_dl = model_parallel_loaders(cfg, train_ds, val_ds, collate, mesh, micro_bs)
     set_seed(cfg.seed)
     torch.manual_seed(cfg.seed)
     towers = [build_model(model_cfg) for _ in range(3)]  # same three initialisations on every rank

@@ -36,9 +36,39 @@ def backend_choice(explicit: Optional[str] = None) -> str:
     return choice
 
 
+def _agree(ok: bool, group, device) -> bool:
+    """True iff `ok` on every rank of `group` (decided over the already working process group)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ok
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def self_test(comm) -> str:
+    """One small all-reduce on the communicator's own stream, waited for with a deadline (``PDT_COMM_SELFTEST_S``,
+    default 60 s) and checked for its value.  Returns "" if it passed, else what went wrong."""
+    world = comm.world_size
+    probe = torch.ones(1024, dtype=torch.float32, device=torch.device("cuda", comm.device))
+    comm.fork()
+    comm.all_reduce_async(probe, False)
+    if not comm.wait_idle(float(os.environ.get("PDT_COMM_SELFTEST_S", "60"))):
+        return "the self-test all-reduce did not finish"
+    comm.join()
+    if not bool((probe == float(world)).all().item()):
+        return f"the self-test all-reduce returned {probe[0].item()} instead of {world}"
+    return ""
+
+
 def create_rccl_comm(group=None, device: Optional[torch.device] = None):
     """Open (once per group) an RcclComm spanning the ranks of `group` (default: all ranks; a process that has
-    no process group gets a 1-rank communicator).  Collective over the group: every member must call it."""
+    no process group gets a 1-rank communicator).  Collective over the group: every member must call it.
+
+    A communicator of more than one rank is self-tested before anybody relies on it: one small all-reduce on its own
+    stream, waited for with a deadline (``PDT_COMM_SELFTEST_S``, default 60 s) and checked for its value.  The ranks
+    agree on the outcome over the process group; if any rank failed to construct the communicator, timed out or read
+    a wrong sum, every rank aborts its communicator and ``None`` is returned - the callers then route the traffic
+    through the process group itself (torch's "nccl" backend) instead of hanging the job."""
     from ..ops import native
 
     if dist.is_initialized():
@@ -65,8 +95,24 @@ def create_rccl_comm(group=None, device: Optional[torch.device] = None):
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group, device=device if dist.get_backend(group) == "nccl" else None)
         uid = box[0]
-    with torch.cuda.device(index):
-        comm = C.RcclComm(uid, rank, world, index)
+    comm, ok, why = None, True, ""
+    try:
+        with torch.cuda.device(index):
+            comm = C.RcclComm(uid, rank, world, index)
+            if world > 1:
+                why = self_test(comm)
+                ok = not why
+    except RuntimeError as e:  # construction or launch failed on this rank
+        ok, why = False, str(e).splitlines()[0]
+    if world > 1 and os.environ.get("PDT_COMM_SELFTEST_FAIL") == str(rank):  # (tests: pretend this rank failed)
+        ok, why = False, "PDT_COMM_SELFTEST_FAIL"
+    if not _agree(ok, group, device):
+        if comm is not None:
+            comm.abort()
+        if why or rank == 0:
+            print(f"[comm] rank {rank}: RcclComm over {world} ranks is not usable"
+                  f"{' (' + why + ')' if why else ' (another rank failed)'}; falling back to the process group", flush=True)
+        comm = None
     _COMMS[key] = comm
     return comm
 
@@ -75,5 +121,6 @@ def close_all() -> None:
     """Orderly teardown of every communicator this process opened (collective: call it on every rank)."""
     with _LOCK:
         for comm in _COMMS.values():
-            comm.close()
+            if comm is not None:
+                comm.close()
         _COMMS.clear()

@@ -107,9 +107,12 @@ def make_reducer(pg, arena: ParamArena, expected: List[int], average: bool = Tru
     label = "c10d:" + (dist.get_backend(pg) if dist.is_initialized() else "none")
     if available():
         comm = None
+        # (PDT_COMM_FORCE_RCCL=1: also try on a gloo group - several ranks sharing one GPU - where RCCL refuses the
+        # duplicate device; the tests use it to run the agreed fall-back)
         if backend_choice(comm_backend) == "rccl" and arena.device.type == "cuda" and (
-                not dist.is_initialized() or dist.get_backend(pg) == "nccl"):
-            comm = create_rccl_comm(None if pg is dist.group.WORLD else pg, arena.device)
+                not dist.is_initialized() or dist.get_backend(pg) == "nccl" or os.environ.get("PDT_COMM_FORCE_RCCL") == "1"):
+            comm = create_rccl_comm(None if pg is dist.group.WORLD else pg, arena.device)  # None: failed its self test
+        if comm is not None:
             red = native().GradBucketReducer(comm, arena.grad, list(arena.bucket_bounds), list(expected), average, code)
             label = "rccl"
         else:

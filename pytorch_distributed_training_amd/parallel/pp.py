@@ -213,7 +213,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     from ..metrics import load_metric
     from ..models.config import preset
     from ..optim import AdamW, get_linear_schedule_with_warmup
-    from ..recipes import _collator, build_datasets
+    from ..recipes import _collator, build_datasets, model_parallel_loaders
     from ..utils.logging import StepLogger
     from ..utils.seed import seed_step, set_seed
     from ..utils.watchdog import StepWatchdog, inject_fault
@@ -238,8 +238,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     accum, micro_bs = cfg.accumulation()
     collate = _collator(cfg, model_cfg)
     # one loader batch = one optimizer step = `accum` pipeline micro-batches
-    train_dl = DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=micro_bs * accum)
-    eval_dl = DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size)
+    train_dl, eval_dl = model_parallel_loaders(cfg, train_ds, val_ds, collate, mesh, micro_bs * accum)
     set_seed(cfg.seed)
     full_state = ckpt._read_weights(cfg.init_from) if cfg.init_from else None
     stage_model = build_stage(model_cfg, mesh.stage, 2, full_state, seed=cfg.seed)

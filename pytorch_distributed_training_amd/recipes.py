@@ -78,6 +78,28 @@ def _collator(cfg: TrainConfig, model_cfg) -> PadCollator:
     return PadCollator(model_cfg.pad_token_id, "longest", pad_to_multiple_of=mult, varlen=varlen)
 
 
+def model_parallel_loaders(cfg: TrainConfig, train_ds, val_ds, collate, mesh, train_batch_size: int):
+    """The (CPU) loaders of the model-parallel recipes, before ``engine.prepare``.
+
+    Default: plain shuffled / sequential loaders, which ``prepare`` shards per batch over the data-parallel replicas
+    (the same flavour as the data-parallel recipe).  ``--compat``: the reference's own loaders
+    (/root/reference/test_model_parallelism.py:254-269) - a ``DistributedSampler`` per split, i.e. per-sample
+    round-robin sharding with the tail padded by repetition, its default ``shuffle=True, seed=0`` for the training
+    AND the evaluation split, and no ``set_epoch`` call, so every epoch sees the same order."""
+    if not cfg.compat:
+        return (DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=train_batch_size),
+                DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size))
+    from .data.loader import _WithSampleIds
+
+    def loader(ds, batch_size):
+        sampler = DistributedShardSampler(ds, num_replicas=mesh.dp, rank=mesh.replica)
+        sampler.frozen = True
+        data = _WithSampleIds(ds) if isinstance(collate, PadCollator) else ds
+        return DataLoader(data, sampler=sampler, collate_fn=collate, batch_size=batch_size)
+
+    return loader(train_ds, train_batch_size), loader(val_ds, cfg.eval_batch_size)
+
+
 def evaluate(engine: Engine, model, eval_dl, metric, dataset_len: int, dedupe: bool) -> dict:
     model.eval()
     seen = 0

@@ -59,7 +59,7 @@ def poll_comm_errors() -> Optional[str]:
     except Exception:  # pragma: no cover - partial installs
         return None
     with _LOCK:  # close_all() takes the same lock: a communicator is never destroyed under this poll
-        for comm in list(_COMMS.values()):
+        for comm in [c for c in _COMMS.values() if c is not None]:
             try:
                 comm.check_async_error()
             except RuntimeError as e:

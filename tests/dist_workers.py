@@ -148,13 +148,13 @@ def dp_recipe(rank, world, tmp):
     return run_data_parallel(cfg)
 
 
-def pipeline_recipe(rank, world, micro_bs, accum):
+def pipeline_recipe(rank, world, micro_bs, accum, compat=False):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
     cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=micro_bs * accum, max_gpu_batch_size=micro_bs, lr=2e-3, num_warmup_steps=1,
-                      log_every=1, max_steps=6, seed=5)
+                      log_every=1, max_steps=6, seed=5, compat=compat)
     return run_model_parallel(rank, world, cfg)
 
 
@@ -267,7 +267,22 @@ def gpu_dp_native(rank, world):
     both = [torch.zeros_like(inner.arena.master) for _ in range(world)]
     dist.all_gather(both, inner.arena.master)
     return {"err": err, "same": bool(torch.equal(both[0], both[1])), "order": list(model.reducer.launch_order()),
-            "nb": model.reducer.num_buckets()}
+            "nb": model.reducer.num_buckets(), "label": model.backend_label}
+
+
+def gpu_dp_comm_fallback(rank, world):
+    os.environ["PDT_COMM_FORCE_RCCL"] = "1"
+    os.environ["PDT_COMM_SELFTEST_FAIL"] = "1"
+    os.environ["PDT_COMM_SELFTEST_S"] = "20"
+    try:
+        out = gpu_dp_native(rank, world)
+        from pytorch_distributed_training_amd.parallel import comm as C
+
+        out["comm_is_none"] = len(C._COMMS) == 1 and all(c is None for c in C._COMMS.values())
+    finally:
+        for k in ("PDT_COMM_FORCE_RCCL", "PDT_COMM_SELFTEST_FAIL", "PDT_COMM_SELFTEST_S"):
+            os.environ.pop(k, None)
+    return out
 
 
 def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop"):

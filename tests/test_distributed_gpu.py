@@ -18,6 +18,14 @@ def test_dp_native_gradients_match_big_batch_two_ranks_one_gpu():
         assert r["order"] == list(range(r["nb"]))
 
 
+def test_unusable_rccl_communicator_falls_back_to_the_process_group():
+    """Two ranks on ONE GPU try to open the framework's RCCL communicator (forced; RCCL refuses the duplicate device,
+    and rank 1 is told to fail its self test anyway): the ranks agree over the process group, abort, and train
+    through the process group with identical replicas."""
+    for r in run_distributed(W.gpu_dp_comm_fallback, 2):
+        assert r["label"] == "c10d:gloo" and r["comm_is_none"] and r["same"] and r["err"] < 2e-2
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_pipeline_native_loss_curve(world):
     """1 or 2 replicas of the 2-stage pipeline against ONE process on the same global batch (16 resp. 32 samples)."""
@@ -157,7 +165,10 @@ comm.p2p([0, 1], [src, dst], [0, 0])          # batched send + recv (to itself: 
 torch.cuda.synchronize()
 assert torch.equal(src, dst)
 comm.barrier(); comm.check_async_error()
-assert comm.collectives() >= 62 and comm.bytes() > 0
+# the start-up self test of multi-rank communicators (bounded wait on the communication stream + value check)
+from pytorch_distributed_training_amd.parallel.comm import self_test
+assert self_test(comm) == "" and comm.wait_idle(1.0)
+assert comm.collectives() >= 63 and comm.bytes() > 0
 close_all()
 print("NATIVE_RCCL_OK")
 '''
