@@ -24,11 +24,11 @@ int main(int argc, char** argv) {
   int64_t st[2] = {1234, 0}; HC(hipMemcpy(rng, st, 16, hipMemcpyHostToDevice));
   PdtRng r{p > 0 ? (const uint64_t*)rng : nullptr, 0, 0};
   const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f); const float sc = p > 0 ? 1.0f / (1.0f - p) : 1.0f;
-  if (pdt_attn_fwd(PDT_F16, qkv, mask, kvl, ctx, lse, B, S, A, sc, thr, r, nullptr)) return 2;
+  if (pdt_attn_fwd(PDT_F16, qkv, mask, kvl, nullptr, ctx, lse, B, S, A, sc, thr, r, nullptr)) return 2;
   hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
   for (int it = 0; it < 3; ++it) {
     HC(hipEventRecord(e0));
-    if (pdt_attn_bwd(PDT_F16, qkv, mask, kvl, ctx, dctx, lse, delta, dqkv, dbias, B, S, A, sc, thr, r, nullptr)) return 3;
+    if (pdt_attn_bwd(PDT_F16, qkv, mask, kvl, nullptr, ctx, dctx, lse, delta, dqkv, dbias, B, S, A, sc, thr, r, nullptr)) return 3;
     HC(hipEventRecord(e1)); HC(hipEventSynchronize(e1));
     float ms; HC(hipEventElapsedTime(&ms, e0, e1));
     printf("kernel %.1f us\n", ms * 1e3);

@@ -1,4 +1,6 @@
 """Rank functions of the multi-process CPU tests (top-level so that mp.spawn can import them)."""
+import os
+
 import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader
