@@ -19,6 +19,7 @@ typedef short short4r __attribute__((__vector_size__(4 * sizeof(short))));
 
 #define PDT_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
 
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane from global memory straight into LDS) -------------
 // Issued through inline asm on purpose.  With the compiler builtin, the waitcnt-insertion pass knows an LDS-DMA
