@@ -16,7 +16,9 @@
 
 namespace pdt {
 
-constexpr int HD = 64;       // head dim
+constexpr int HD = 64;       // head dim (the MFMA tiling of every kernel here is built on it; the model checks it)
+constexpr float ATT_SCALE = 0.125f;  // 1 / sqrt(HD)
+static_assert(ATT_SCALE * ATT_SCALE * HD == 1.0f, "softmax scale must be 1 / sqrt(head dim)");
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int ATT_WAVES = 8;  // waves per workgroup: 8 x 16 = 128 query rows (or keys) share one K/V (or Q/dO) image
 constexpr int ATT_THREADS = ATT_WAVES * 64;
@@ -37,7 +39,7 @@ struct AttnArgs {
   float* delta;      // [B, A, S]
   void* dqkv;        // [B*S, 3H]
   int B, S, A, H;
-  float scale;       // 1/sqrt(64)
+  float scale;       // 1 / sqrt(head dim)
   float drop_scale;
   uint32_t drop_thr;  // round(p * 65536), 0 = off
   RngArgs rng;
@@ -738,7 +740,7 @@ extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, con
   if (!cu && (!mask || !kv_len)) return -3;
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.cu = cu; a.ctx = ctx; a.lse = lse;
-  a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = 0.125f;
+  a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = ATT_SCALE;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
   return dtype == PDT_F16 ? attn_dispatch<_Float16>(0, a, (hipStream_t)stream) : attn_dispatch<__bf16>(0, a, (hipStream_t)stream);
 }
@@ -769,7 +771,7 @@ extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, con
   AttnArgs a{};
   a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.cu = cu; a.octx = ctx; a.dctx = dctx; a.lse = const_cast<float*>(lse);
   a.delta = delta; a.dqkv = dqkv;
-  a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = 0.125f;
+  a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = ATT_SCALE;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
   hipStream_t s = (hipStream_t)stream;
   if (S <= 128) return dtype == PDT_F16 ? launch_fused128<_Float16>(a, dbias, s) : launch_fused128<__bf16>(a, dbias, s);

@@ -258,11 +258,13 @@ def _torchrun_bench(extra, port, timeout=240):
 
 
 def test_bench_two_ranks_share_the_gpu_data_parallel_and_pipeline():
-    """bench.py under the launcher with two ranks on the one GPU (gloo rehearsal), at a size where the large-shape
-    GEMMs take their persistent launch path: data parallel (bucket reducer staged through the host) and
-    DP x 2-stage pipeline in fp16 (overflow flag agreed across the stages)."""
+    """bench.py under the launcher with two ranks on the one GPU (gloo rehearsal; multi-rank runs launch every GEMM with
+    one workgroup per tile - the Engine switches the persistent launch off): data parallel (bucket reducer staged
+    through the host) and DP x 2-stage pipeline in fp16 (overflow flag agreed across the stages)."""
+    assert_mode = 0  # what bench.py must report as gemm_persistent_mode for a multi-rank run
     dp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"], 29641)
     assert dp["n_gpus"] == 2 and dp["config"]["parallelism"] == "dp2" and dp["value"] > 0
+    assert dp["config"]["gemm_persistent_mode"] == assert_mode and dp["replicas_bit_equal"] is True
     assert dp["final_loss"] == dp["final_loss"] and dp["comm_exposed_ms_per_step"] is not None
     pp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "256", "--pp", "2", "--micro-batches", "4"], 29642)
     assert pp["config"]["parallelism"].startswith("dp1 x pp2") and pp["value"] > 0
