@@ -110,6 +110,15 @@ int pdt_layernorm_bwd_max_blocks(void);
 // partial is [nblk][nseg][H]; out_j[c] (+)= sum_b partial[b][j][c] for each non-null out_j (nseg <= 4)
 int pdt_colsum_finish(const float* partial, int nblk, int H, int nseg, float* o0, float* o1, float* o2, float* o3,
                       int accumulate, void* stream);
+// Several finishing jobs in ONE launch (a layer's backward produces four sets of partial sums; with short micro-batches
+// the launches, not the sums, are what they cost).  Job j is pdt_colsum_finish(partial, nblk, H, nseg, out..., accumulate).
+typedef struct PdtColsumJob {
+  const float* partial;
+  float* out[4];
+  int nblk, H, nseg, accumulate;
+} PdtColsumJob;
+#define PDT_COLSUM_MAX_JOBS 6
+int pdt_colsum_finish_multi(const PdtColsumJob* jobs, int njobs, void* stream);
 // partial[nblk][ncols] column sums of a 16-bit [rows, ld] matrix (bias gradients)
 int pdt_colsum_partial(int dtype, const void* x, int rows, int ncols, int ld, float* partial, int* nblk, void* stream);
 

@@ -153,12 +153,12 @@ struct ColsumOuts { float* out[4]; };
 // Each block owns 32 columns: 32 row groups x 32 columns; a thread sums every 32nd partial row of its column
 // (coalesced 128-B reads across the 32 lanes, 4 independent accumulators to keep loads in flight), then the
 // row groups are combined in a fixed order through LDS.
-__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblk, int H,
-                                                             int nseg, ColsumOuts outs, int accumulate) {
+__device__ __forceinline__ void colsum_finish_body(const float* __restrict__ partial, int nblk, int H, int nseg,
+                                                   float* const (&out)[4], int accumulate, int block) {
   __shared__ float red[32][33];
   const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int total = nseg * H;
-  const int idx = blockIdx.x * 32 + cg;
+  const int idx = block * 32 + cg;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (idx < total) {
     int b = rg;
@@ -177,9 +177,27 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 32; ++r) t += red[r][cg];
     const int seg = idx / H, c = idx % H;
-    float* o = seg == 0 ? outs.out[0] : (seg == 1 ? outs.out[1] : (seg == 2 ? outs.out[2] : outs.out[3]));
+    float* o = seg == 0 ? out[0] : (seg == 1 ? out[1] : (seg == 2 ? out[2] : out[3]));
     if (o) o[c] = accumulate ? o[c] + t : t;
   }
+}
+
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int nblk, int H,
+                                                             int nseg, ColsumOuts outs, int accumulate) {
+  colsum_finish_body(partial, nblk, H, nseg, outs.out, accumulate, blockIdx.x);
+}
+
+// several jobs in one launch: block -> job through the running block counts (first[j] = first block of job j)
+struct ColsumJobs {
+  PdtColsumJob job[PDT_COLSUM_MAX_JOBS];
+  int first[PDT_COLSUM_MAX_JOBS + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(1024) void colsum_finish_multi_kernel(ColsumJobs js) {
+  int j = 0;
+  while (j + 1 < js.njobs && (int)blockIdx.x >= js.first[j + 1]) ++j;  // block-uniform
+  const PdtColsumJob& q = js.job[j];
+  colsum_finish_body(q.partial, q.nblk, q.H, q.nseg, q.out, q.accumulate, (int)blockIdx.x - js.first[j]);
 }
 
 // column partial sums of a 16-bit matrix: grid (ceil(ncols/2048), nblk); 64 rows per block row
@@ -280,6 +298,22 @@ extern "C" int pdt_colsum_finish(const float* partial, int nblk, int H, int nseg
   const int total = nseg * H;
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, nblk,
                      H, nseg, outs, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_colsum_finish_multi(const PdtColsumJob* jobs, int njobs, void* stream) {
+  if (njobs < 1 || njobs > PDT_COLSUM_MAX_JOBS) return -3;
+  ColsumJobs js{};
+  js.njobs = njobs;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (jobs[j].nseg < 1 || jobs[j].nseg > 4 || jobs[j].H < 1 || jobs[j].nblk < 0 || !jobs[j].partial) return -3;
+    js.job[j] = jobs[j];
+    js.first[j] = blocks;
+    blocks += (jobs[j].nseg * jobs[j].H + 31) / 32;
+  }
+  js.first[njobs] = blocks;
+  hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, js);
   return (int)hipGetLastError();
 }
 

@@ -144,6 +144,31 @@ PdtRng make_rng(const Tensor& state, int64_t micro, int64_t site, const OptTenso
 // ---------------------------------------------------------------------------------------------------
 // GEMM wrappers.  2-D operands; leading dimension = stride(0).
 // ---------------------------------------------------------------------------------------------------
+// Column-sum finishing jobs (bias / gamma / beta gradients) of one layer backward, launched together at its end: with
+// short micro-batches a layer's backward is a chain of ~15 launches of 5-40 us each, and four of them were finishers.
+// The partial-sum tensors are kept alive until the launch; flush() runs on the caller's current stream, which must be
+// the one their producers ran on.
+class FinishQueue {
+ public:
+  void add(const Tensor& partial, int nblk, int H, int nseg, float* o0, float* o1, float* o2, bool accumulate) {
+    if (n_ == PDT_COLSUM_MAX_JOBS) flush();
+    keep_.push_back(partial);
+    jobs_[n_++] = PdtColsumJob{partial.data_ptr<float>(), {o0, o1, o2, nullptr}, nblk, H, nseg, accumulate ? 1 : 0};
+  }
+  void flush() {
+    if (!n_) return;
+    check(pdt_colsum_finish_multi(jobs_, n_, cur_stream()), "colsum_finish_multi");
+    n_ = 0;
+    keep_.clear();
+  }
+  // (no flush in the destructor: it would launch, and possibly throw, while an exception unwinds the layer)
+
+ private:
+  PdtColsumJob jobs_[PDT_COLSUM_MAX_JOBS];
+  int n_ = 0;
+  std::vector<Tensor> keep_;
+};
+
 struct Epi {
   int kind = PDT_EPI_PLAIN;
   const Tensor* bias = nullptr;
@@ -153,6 +178,7 @@ struct Epi {
   PdtRng rng{nullptr, 0, 0};
   Tensor* colsum = nullptr;  // fp32 [N]: (+)= column sums of the stored output (a bias gradient)
   bool colsum_accumulate = true;
+  FinishQueue* fq = nullptr;  // the finishing pass of `colsum` is queued here instead of being launched at once
 };
 
 void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, int N, int K, const Epi& e, int tile = -1) {
@@ -184,7 +210,9 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
     g.ws_splits = splits;
   }
   check(pdt_gemm(dt_code(A), layout, tile, &g, cur_stream()), "gemm");
-  if (e.colsum)
+  if (e.colsum && e.fq)
+    e.fq->add(cs_part, g.colsum_rows, N, 1, e.colsum->data_ptr<float>(), nullptr, nullptr, e.colsum_accumulate);
+  else if (e.colsum)
     check(pdt_colsum_finish(cs_part.data_ptr<float>(), g.colsum_rows, N, 1, e.colsum->data_ptr<float>(), nullptr, nullptr,
                             nullptr, e.colsum_accumulate ? 1 : 0, cur_stream()), "colsum_finish");
 }
@@ -247,7 +275,7 @@ void colsum_into(const Tensor& X, Tensor& out, bool accumulate) {
 struct LnBwdOut { Tensor dx, ddrop; };
 // LayerNorm backward + (optional) dropout-masked copy + gamma/beta/bias gradients
 LnBwdOut ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Tensor& gamma, Tensor* g_gamma,
-                Tensor* g_beta, Tensor* g_bias, double drop_p, PdtRng rng, bool accumulate) {
+                Tensor* g_beta, Tensor* g_bias, double drop_p, PdtRng rng, bool accumulate, FinishQueue* fq = nullptr) {
   const int rows = (int)x.size(0), H = (int)x.size(1);
   LnBwdOut o;
   o.dx = at::empty_like(x);
@@ -258,9 +286,14 @@ LnBwdOut ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& stats, const Te
   check(pdt_layernorm_bwd(dt_code(x), dy.data_ptr(), x.data_ptr(), stats.data_ptr<float>(), gamma.data_ptr(),
                           o.dx.data_ptr(), masked ? o.ddrop.data_ptr() : nullptr, partial.data_ptr<float>(), &nblk,
                           rows, H, keep_scale(drop_p), thr16(drop_p), rng, cur_stream()), "layernorm_bwd");
-  check(pdt_colsum_finish(partial.data_ptr<float>(), nblk, H, 3, g_gamma ? g_gamma->data_ptr<float>() : nullptr,
-                          g_beta ? g_beta->data_ptr<float>() : nullptr, g_bias ? g_bias->data_ptr<float>() : nullptr,
-                          nullptr, accumulate ? 1 : 0, cur_stream()), "colsum_finish");
+  float* o0 = g_gamma ? g_gamma->data_ptr<float>() : nullptr;
+  float* o1 = g_beta ? g_beta->data_ptr<float>() : nullptr;
+  float* o2 = g_bias ? g_bias->data_ptr<float>() : nullptr;
+  if (fq)
+    fq->add(partial, nblk, H, 3, o0, o1, o2, accumulate);
+  else
+    check(pdt_colsum_finish(partial.data_ptr<float>(), nblk, H, 3, o0, o1, o2, nullptr, accumulate ? 1 : 0, cur_stream()),
+          "colsum_finish");
   return o;
 }
 
@@ -344,12 +377,13 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   const int T = (int)x.size(0), H = (int)x.size(1);
   const int64_t site = layer * 4;
 
+  FinishQueue fq;  // the four column-sum finishers of the layer run as one launch at its end
   // LN2 -> dz2 (residual path) and ddrop2 (through the FFN2 output dropout); d gamma/beta/b2
   LnBwdOut l2 = ln_bwd(dy, z2, stats2, w[10], &gr[10], &gr[11], &gr[9], p_hidden, make_rng(rng_state, micro, site + 2, sids, S, B, rowmap),
-                       accumulate);
+                       accumulate, &fq);
   // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU) ; wgrad
   Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
-  e_dg.colsum = &gr[7]; e_dg.colsum_accumulate = accumulate;
+  e_dg.colsum = &gr[7]; e_dg.colsum_accumulate = accumulate; e_dg.fq = &fq;
   WgradLane lane(g_wgrad_mode == 2 || (g_wgrad_mode == 1 && T <= kWgradLaneMaxTokens));
   lane.run([&] { gemm_tn_into(l2.ddrop, gact, gr[8], accumulate); });
   Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
@@ -359,7 +393,7 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   Tensor dx1 = gemm_nn(du, w[6], e_add);
   // LN1
   LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1, sids, S, B, rowmap),
-                       accumulate);
+                       accumulate, &fq);
   // attention output projection
   lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); });
   Tensor dctx = gemm_nn(l1.ddrop, w[2], Epi{});
@@ -375,14 +409,14 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
                      thr16(p_attn), make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()),
         "attn_bwd");
   if (fused_db)
-    check(pdt_colsum_finish(db_part.data_ptr<float>(), (int)B, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, nullptr,
-                            accumulate ? 1 : 0, cur_stream()), "colsum_finish");
+    fq.add(db_part, (int)B, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, accumulate);
   else
     colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
   Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
   lane.run([&] { gemm_tn_into(dqkv, x, gr[0], accumulate); });
   Tensor dx = gemm_nn(dqkv, w[0], e_add2);
+  fq.flush();
   lane.join();  // the layer's gradients are complete on the main stream from here (bucket all-reduce, next layer)
   (void)T; (void)H;
   return dx;
