@@ -210,9 +210,10 @@ class Engine:
         it.  The two are independent - the weights only change at the optimizer step - and with the reference's
         8-sample micro-batches (/root/reference/test_data_parallelism.py:90-93) neither fills the GPU on its own:
         a 1024-token GEMM has 64-256 output tiles for 256 CUs.  Every micro-batch lives on ONE stream (forward
-        and backward, which is also where autograd runs a node's backward), consecutive backward passes are
-        ordered by events because they accumulate into the same gradient arena, and the caller's stream waits for
-        both before the optimizer step.  The arithmetic is that of the plain loop."""
+        and backward, which is also where autograd runs a node's backward); even and odd micro-batches accumulate
+        into two gradient buffers that the last backward merges (``PDT_DUAL_BACKWARD=0``: into one buffer, with the
+        backward passes ordered by events - bit-identical to the plain loop), and the caller's stream waits for
+        both streams before the optimizer step."""
         n = len(batches)
         dp = model if isinstance(model, DataParallel) else None
         if overlap is None:
@@ -243,9 +244,21 @@ class Engine:
                 for t in b.values():
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(self._alt_stream)
+            # Two gradient lanes (default; PDT_DUAL_BACKWARD=0 keeps one): micro-batch i accumulates into lane i % 2, a gradient buffer of
+            # its own, so the backward passes of the two streams need no ordering between them and each stream runs its
+            # micro-batches (forward, backward, forward, ...) independently of the other.  The last backward of the
+            # window waits for the other stream and folds the second lane into the first segment by segment, right
+            # before each segment is handed to the data-parallel reducer.  The sum is the same set of terms added in a
+            # different (fixed) order than the one-lane loop.
+            rt = getattr(self.unwrap_model(model), "runtime", None)
+            dual = rt is not None and os.environ.get("PDT_DUAL_BACKWARD", "1") != "0"
+            if dual:
+                rt.arena.enable_alt()
 
             def forward(i):
                 with torch.cuda.stream(streams[i % 2]):
+                    if dual:
+                        rt.lane = i % 2  # (captured by the nodes of this forward pass; one forward runs at a time)
                     out = model(**batches[i])
                     loss = out.loss / n
                     if self.scaler.enabled:
@@ -264,24 +277,37 @@ class Engine:
 
             split_k = _native().gemm_split_k()
             _native().set_gemm_split_k(False)  # two chains share the CUs: fewer launches beat shorter GEMMs here
-            cur, done = forward(0), None
+            cur, done = forward(0), [None, None]
             for i in range(n):
                 nxt = None
                 if i + 1 < n:  # started BEFORE backward(i): runs concurrently with it
                     nxt = self._fwd_pool.submit(forward, i + 1) if threaded else forward(i + 1)
                 s = streams[i % 2]
                 with torch.cuda.stream(s):
-                    if done is not None:
-                        s.wait_event(done)  # backward passes accumulate into one arena: strictly one after the other
+                    other = done[(i + 1) % 2]
+                    if other is not None and (not dual or i == n - 1):
+                        # one lane: backward passes accumulate into one buffer, strictly one after the other;
+                        # two lanes: only the merging (last) backward has to see the other stream's gradients
+                        s.wait_event(other)
                     if dp is not None:
                         dp.require_sync = i == n - 1
                         if i == n - 1:
                             dp.prepare_backward()
-                    cur[1].backward()
-                    done = torch.cuda.Event()
-                    done.record(s)
+                    if dual and i == n - 1:
+                        rt.merge_on_done = True
+                    try:
+                        cur[1].backward()
+                    finally:
+                        if dual:
+                            rt.merge_on_done = False
+                    if dual and i == n - 1:
+                        rt.arena.merge_alt()  # (segments that no node of the last backward reported)
+                    done[i % 2] = torch.cuda.Event()
+                    done[i % 2].record(s)
                 losses.append(cur[0].loss.detach())
                 cur = nxt.result() if (threaded and nxt is not None) else nxt
+            if dual:
+                rt.lane = 0
             tail = torch.cuda.Event()  # the caller's stream continues after everything on the second stream
             tail.record(self._alt_stream)
             main.wait_event(tail)

@@ -154,6 +154,8 @@ class ParamArena:
             for seg in self.segments:
                 seg.bucket = min(seg.bucket, len(self.bucket_bounds) - 2)
         self.written = [False] * len(self.segments)  # gradient slice holds this step's values already
+        self.grad_alt: Optional[torch.Tensor] = None  # second gradient lane (enable_alt)
+        self.written_alt: List[bool] = []
         self.window = 0  # accumulation windows started so far (= optimizer steps taken, on every rank alike)
         self.seg_index = {s.name: i for i, s in enumerate(self.segments)}
         self.param_segment: Dict[int, int] = {id(p): i for i, s in enumerate(self.segments) for _, p in s.params}
@@ -217,12 +219,41 @@ class ParamArena:
             n *= s
         return self.p16[o:o + n].view(*shape)
 
-    def gview(self, name: str, shape: Sequence[int]) -> torch.Tensor:
+    def gview(self, name: str, shape: Sequence[int], lane: int = 0) -> torch.Tensor:
         o, _ = self.offsets[name]
         n = 1
         for s in shape:
             n *= s
-        return self.grad[o:o + n].view(*shape)
+        return (self.grad if lane == 0 else self.grad_alt)[o:o + n].view(*shape)
+
+    # -- second gradient lane ---------------------------------------------------------------------------
+    # Two backward passes that accumulate into ONE buffer must run one after the other.  With a second full-size
+    # gradient buffer (1.3 GB for BERT-large: nothing next to 288 GB) the micro-batches of an accumulation window
+    # alternate between two lanes whose backward passes run concurrently; merge_alt() adds the second lane into
+    # the first before anything (bucket all-reduce, overflow check, optimizer) reads the gradients.
+    def enable_alt(self) -> None:
+        if self.grad_alt is None:
+            self.grad_alt = torch.zeros_like(self.grad)
+            self.written_alt = [False] * len(self.segments)
+
+    def merge_alt(self, seg_idx: Optional[int] = None) -> None:
+        """grad (+)= grad_alt for one segment (or all) that the second lane wrote in this window."""
+        if self.grad_alt is None:
+            return
+        for i in (range(len(self.segments)) if seg_idx is None else (seg_idx,)):
+            if not self.written_alt[i]:
+                continue
+            seg = self.segments[i]
+            dst, src = self.grad[seg.start:seg.end], self.grad_alt[seg.start:seg.end]
+            overwrite = seg.native_overwrite and self.p16 is not None and self.master.is_cuda and not self.written[i]
+            if overwrite:
+                dst.copy_(src)  # (the first lane never touched the slice: it may hold the previous window's values)
+            else:
+                dst.add_(src)
+            self.written[i] = True
+            self.written_alt[i] = False
+            if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):
+                src.zero_()  # accumulate-only producers (the head) expect zeros at their first touch
 
     def mview(self, name: str, shape: Sequence[int]) -> torch.Tensor:
         o, _ = self.offsets[name]
@@ -258,6 +289,10 @@ class ParamArena:
             self.written[i] = False
             if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):
                 self.grad[seg.start:seg.end].zero_()
+            if self.grad_alt is not None and self.written_alt[i]:  # (a window that ended without its merge)
+                self.written_alt[i] = False
+                if not (seg.native_overwrite and self.p16 is not None and self.master.is_cuda):
+                    self.grad_alt[seg.start:seg.end].zero_()
 
     def zero_unwritten(self) -> None:
         """Before the optimizer reads the gradients: a slice that zero_grad() left alone because its native producer
@@ -269,10 +304,11 @@ class ParamArena:
             if seg.native_overwrite and not self.written[i]:
                 self.grad[seg.start:seg.end].zero_()
 
-    def take_accumulate_flag(self, seg_idx: int) -> bool:
-        """True if the native producer must add to the slice, False if it may overwrite it."""
-        acc = self.written[seg_idx]
-        self.written[seg_idx] = True
+    def take_accumulate_flag(self, seg_idx: int, lane: int = 0) -> bool:
+        """True if the native producer must add to the slice (of gradient lane `lane`), False if it may overwrite it."""
+        flags = self.written if lane == 0 else self.written_alt
+        acc = flags[seg_idx]
+        flags[seg_idx] = True
         return acc
 
     def state_bytes(self) -> int:

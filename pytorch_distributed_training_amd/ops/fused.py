@@ -58,6 +58,12 @@ class NativeRuntime:
         # its native node (the word-embedding table of a tower-parallel rank, filled by a second backward call)
         self.hold: set = set()
         self._held: List[int] = []
+        # gradient lane of the forward pass in progress (ParamArena.enable_alt): captured by every native node, its
+        # backward writes the parameter gradients of that lane.  merge_on_done: the backward in progress is the last
+        # of its accumulation window - each segment's second lane is added to the first as soon as the segment is done,
+        # i.e. before the data-parallel reducer sees it.
+        self.lane = 0
+        self.merge_on_done = False
 
     def reseed(self, seed: int) -> None:
         self.rng_state[0] = seed
@@ -81,6 +87,8 @@ class NativeRuntime:
         return self.key
 
     def done(self, seg: int) -> None:
+        if self.merge_on_done:
+            self.arena.merge_alt(seg)
         if seg in self.hold:
             self._held.append(seg)
         elif self.segment_done is not None:
@@ -114,10 +122,18 @@ class LayerNative:
         ]
         self.w: List[torch.Tensor] = [arena.view16(n, s) for n, s in spec]
         self.g: List[torch.Tensor] = [arena.gview(n, s) for n, s in spec]
+        self._spec, self._g_alt = spec, None
         self.segment = segment
         self.rt = runtime
         self.arena = arena
         self.site_offset = 0  # distinguishes the dropout streams of equal layer indices in different towers
+
+    def grads(self, lane: int) -> List[torch.Tensor]:
+        if lane == 0:
+            return self.g
+        if self._g_alt is None:
+            self._g_alt = [self.arena.gview(n, s, 1) for n, s in self._spec]
+        return self._g_alt
 
 
 class _LayerFn(torch.autograd.Function):
@@ -137,6 +153,7 @@ class _LayerFn(torch.autograd.Function):
             cfg.layer_norm_eps, key.counter, layer.index + nat.site_offset, key.sample_ids, mask.cu, mask.rowmap)
         ctx.layer, ctx.mask, ctx.x2, ctx.saved = layer, (m, kvl, mask.cu, mask.rowmap), x2, outs[1:]
         ctx.meta = (B, S, H, train, key, packed)
+        ctx.lane = nat.rt.lane
         return outs[0] if packed else outs[0].view(B, S, H)
 
     @staticmethod
@@ -145,9 +162,9 @@ class _LayerFn(torch.autograd.Function):
         nat: LayerNative = layer._native
         cfg = layer.cfg
         B, S, H, train, key, packed = ctx.meta
-        acc = nat.arena.take_accumulate_flag(nat.segment)
+        acc = nat.arena.take_accumulate_flag(nat.segment, ctx.lane)
         dx = native().layer_backward(
-            dy.reshape(-1, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.g, key.state,
+            dy.reshape(-1, H), ctx.x2, list(ctx.saved), ctx.mask[0], ctx.mask[1], nat.w, nat.grads(ctx.lane), key.state,
             B, S, cfg.num_attention_heads,
             cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
             key.counter, layer.index + nat.site_offset, acc, key.sample_ids, ctx.mask[2], ctx.mask[3])
@@ -180,8 +197,11 @@ class EmbedNative:
         ]
         self.w = [arena.view16(n, s) for n, s in spec]
         self.g = [arena.gview(n, s) for n, s in spec]
+        self._spec, self._g_alt = spec, None
         self.segment, self.rt, self.arena = segment, runtime, arena
         self.site_offset = 0
+
+    grads = LayerNative.grads
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -201,6 +221,7 @@ class _EmbedFn(torch.autograd.Function):
                                                SITE_EMBED + nat.site_offset, key.sample_ids, S, rowmap)
         ctx.emb, ctx.idx, ctx.saved = emb, (idf, pf, tf), (pre, stats)
         ctx.meta = (B, S, train, key, ie is not None, rowmap)
+        ctx.lane = nat.rt.lane
         return y if rowmap is not None else y.view(B, S, cfg.hidden_size)
 
     @staticmethod
@@ -211,8 +232,8 @@ class _EmbedFn(torch.autograd.Function):
         B, S, train, key, has_ie, rowmap = ctx.meta
         idf, pf, tf = ctx.idx
         pre, stats = ctx.saved
-        acc = nat.arena.take_accumulate_flag(nat.segment)
-        dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.g,
+        acc = nat.arena.take_accumulate_flag(nat.segment, ctx.lane)
+        dsum = native().embed_backward(dy.reshape(B * S, -1), pre, stats, idf, pf, tf, nat.w[3], nat.grads(ctx.lane),
                                        key.state, cfg.hidden_dropout_prob if train else 0.0, key.counter,
                                        SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc, key.sample_ids, S, rowmap)
         ctx.saved = None
@@ -242,14 +263,26 @@ class DenseNative:
     def __init__(self, arena: ParamArena, wname: str, bname: str, H: int, segment: int, runtime: NativeRuntime):
         self.w, self.b = arena.view16(wname, (H, H)), arena.view16(bname, (H,))
         self.gw, self.gb = arena.gview(wname, (H, H)), arena.gview(bname, (H,))
+        self._names, self._alt = (wname, (H, H), bname, (H,)), None
         self.segment, self.rt, self.arena = segment, runtime, arena
+
+    def grads(self, lane: int):
+        """(weight gradient, bias gradient) views of gradient lane `lane`; these producers always ADD, so a write into
+        the second lane is flagged here for the merge."""
+        if lane == 0:
+            return self.gw, self.gb
+        if self._alt is None:
+            wn, ws, bn, bs = self._names
+            self._alt = (self.arena.gview(wn, ws, 1), self.arena.gview(bn, bs, 1))
+        self.arena.written_alt[self.segment] = True
+        return self._alt
 
 
 class _DenseTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, first, nat):
         out = native().dense_tanh_forward(first, nat.w, nat.b)
-        ctx.nat = nat
+        ctx.nat, ctx.lane = nat, nat.rt.lane
         # an OUTPUT kept as a plain ctx attribute would close a reference cycle (ctx -> out -> grad_fn -> ctx)
         # that keeps the whole graph and its activations alive until the cycle collector runs
         ctx.save_for_backward(first, out)
@@ -260,7 +293,8 @@ class _DenseTanhFn(torch.autograd.Function):
         nat: DenseNative = ctx.nat
         first, out = ctx.saved_tensors
         dpre = (dout.float() * (1.0 - out.float() ** 2)).to(out.dtype)
-        dfirst = native().dense_backward(dpre.contiguous(), first, nat.w, nat.gw, nat.gb, True)
+        gw, gb = nat.grads(ctx.lane)
+        dfirst = native().dense_backward(dpre.contiguous(), first, nat.w, gw, gb, True)
         nat.rt.done(nat.segment)  # the dense layer is the last producer of the head segment in backward order
         return dfirst, None
 
@@ -276,7 +310,10 @@ class HeadNative:
     def __init__(self, arena: ParamArena, wname: str, bname: str, C: int, H: int, segment: int, runtime: NativeRuntime):
         self.w, self.b = arena.mview(wname, (C, H)), arena.mview(bname, (C,))
         self.gw, self.gb = arena.gview(wname, (C, H)), arena.gview(bname, (C,))
+        self._names, self._alt = (wname, (C, H), bname, (C,)), None
         self.segment, self.rt, self.arena = segment, runtime, arena
+
+    grads = DenseNative.grads
 
 
 class _HeadFn(torch.autograd.Function):
@@ -286,7 +323,7 @@ class _HeadFn(torch.autograd.Function):
     def forward(ctx, pooled, nat, labels, p, site):
         key = nat.rt.key
         logits, loss = native().head_forward(pooled, nat.w, nat.b, labels, key.state, p, key.counter, site, key.sample_ids)
-        ctx.nat, ctx.has_labels = nat, labels is not None
+        ctx.nat, ctx.has_labels, ctx.lane = nat, labels is not None, nat.rt.lane
         ctx.save_for_backward(pooled, logits, *([labels] if labels is not None else []))  # logits is an output
         ctx.meta = (p, key, site)
         ctx.set_materialize_grads(False)  # an unused output arrives as None instead of a zero tensor
@@ -298,8 +335,9 @@ class _HeadFn(torch.autograd.Function):
         p, key, site = ctx.meta
         pooled, logits = ctx.saved_tensors[:2]
         labels = ctx.saved_tensors[2] if ctx.has_labels else None
+        gw, gb = nat.grads(ctx.lane)
         dp = native().head_backward(dloss if labels is not None else None, dlogits, pooled, nat.w, logits,
-                                    labels, nat.gw, nat.gb, key.state, p, key.counter, site, True, False, key.sample_ids)
+                                    labels, gw, gb, key.state, p, key.counter, site, True, False, key.sample_ids)
         return dp, None, None, None, None
 
 

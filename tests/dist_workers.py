@@ -272,6 +272,36 @@ def gpu_dp_native(rank, world):
             "nb": model.reducer.num_buckets(), "label": model.backend_label}
 
 
+def gpu_dp_accumulate_two_lanes(rank, world):
+    """An accumulation window of 4 micro-batches per rank through Engine.accumulate (two streams, two gradient lanes,
+    the all-reduce armed for the last micro-batch, whose backward merges the lanes segment by segment in front of the
+    reducer): the reduced gradient equals the gradient of ONE process on the 32 samples of both ranks."""
+    eng = Engine(fp16=True, seed=7, min_bucket_mb=0.05, init_scale=256.0)
+    model = _model(seed=rank)
+    opt = AdamW(params=model.parameters(), lr=1e-3)
+    model, opt = eng.prepare(model, opt)
+    inner = eng.unwrap_model(model)
+    batch = {k: v.cuda() for k, v in _global_batch(32).items()}
+    shard = {k: v[rank::world] for k, v in batch.items()}
+    micro = [{k: v[4 * i:4 * i + 4] for k, v in shard.items()} for i in range(4)]
+    model.train()
+    eng.accumulate(model, micro)
+    torch.cuda.synchronize()
+    g_dp = inner.arena.grad.clone() / eng.scaler.get_scale()
+    ref = _model(seed=0).cuda()
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+
+    arena = ParamArena(ref, eng.device, torch.float16)
+    ref.enable_native(arena, seed=1)
+    ref.train()
+    ref(**batch).loss.backward()
+    err = ((g_dp - arena.grad).norm() / arena.grad.norm()).item()
+    opt.step(); opt.zero_grad()
+    model.check_replicas()
+    return {"err": err, "lanes": inner.arena.grad_alt is not None, "order": list(model.reducer.launch_order()),
+            "nb": model.reducer.num_buckets()}
+
+
 def gpu_dp_comm_fallback(rank, world):
     os.environ["PDT_COMM_FORCE_RCCL"] = "1"
     os.environ["PDT_COMM_SELFTEST_FAIL"] = "1"

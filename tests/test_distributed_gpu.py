@@ -18,6 +18,12 @@ def test_dp_native_gradients_match_big_batch_two_ranks_one_gpu():
         assert r["order"] == list(range(r["nb"]))
 
 
+def test_dp_accumulation_window_with_two_gradient_lanes_two_ranks_one_gpu():
+    for r in run_distributed(W.gpu_dp_accumulate_two_lanes, 2):
+        assert r["lanes"] and r["err"] < 2e-2, r
+        assert r["order"] == list(range(r["nb"]))
+
+
 def test_unusable_rccl_communicator_falls_back_to_the_process_group():
     """Two ranks on ONE GPU try to open the framework's RCCL communicator (forced; RCCL refuses the duplicate device,
     and rank 1 is told to fail its self test anyway): the ranks agree over the process group, abort, and train
