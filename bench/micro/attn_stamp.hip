@@ -2,6 +2,8 @@
 // wave 0 of every workgroup leaves 100-MHz time stamps (start, first fill done, after barrier, after dQ sweep,
 // after the re-fill, after dK/dV sweep, end) in the delta buffer; prints the mean phase durations and the workgroup lifetime.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPDT_ATT_STAMP attn_stamp.hip -o attn_stamp
+// Ablations: add -DPDT_ATT_NOCOMPUTE=1 (both sweeps compiled out: the kernel's memory traffic alone) and / or
+// -DPDT_ATT_NOSTORE=1 (dQ / dK / dV not written).  Usage: attn_stamp [batch = 256] [dropout p = 0.1]
 #include "../../csrc/kernels/attention.hip"
 #include <cstdio>
 #include <vector>

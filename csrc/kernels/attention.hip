@@ -464,6 +464,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x121>(v);  // row_ror:1
   return v;
 }
+// bench/micro/attn_stamp.hip builds this file with PDT_ATT_NOCOMPUTE=1 (both sweeps of the fused backward compiled out:
+// what is left is its memory traffic) and / or PDT_ATT_NOSTORE=1 (dQ / dK / dV are not written)
+#ifndef PDT_ATT_NOCOMPUTE
+#define PDT_ATT_NOCOMPUTE 0
+#endif
+#ifndef PDT_ATT_NOSTORE
+#define PDT_ATT_NOSTORE 0
+#endif
 #ifndef PDT_ATT_FUSED_WAVES_EU  // minimum waves per SIMD the register allocation of the fused kernel must allow
 #define PDT_ATT_FUSED_WAVES_EU 4
 #endif
@@ -567,7 +575,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   float4v dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
-  if (r0 < S) {
+  if (r0 < S && !PDT_ATT_NOCOMPUTE) {
     const int q = r0 + lm;
     // exp2(score2 + mask - lse2q) = p * scale: the softmax scale of dS is folded into the exponent
     const float lse2q = lse_s[q] - __log2f(a.scale), ndelta = -del_s[q];
@@ -606,7 +614,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   __syncthreads();
   if (r0 < S) {
     const int q = r0 + lm;
-    store_tile16x64<T>((T*)a.dqkv + ((size_t)row0 + min(q, S - 1)) * ld + h * HD, dq, 1.0f, g, q < S);
+    store_tile16x64<T>((T*)a.dqkv + ((size_t)row0 + min(q, S - 1)) * ld + h * HD, dq, 1.0f, g, q < S && !PDT_ATT_NOSTORE);
     if (dbias) {  // rows >= S are exactly zero (zero Q / dO fragments, p = 0)
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
@@ -634,7 +642,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   float4v dk_[4], dv_[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
-  if (kv_active) {
+  if (kv_active && !PDT_ATT_NOCOMPUTE) {
     const uint32_t kmul = (uint32_t)key * ATT_GOLD;
     const float dsc2 = a.drop_scale * a.scale;
 #pragma unroll
@@ -677,8 +685,8 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   }
   {
     T* outk = (T*)a.dqkv + ((size_t)row0 + min(key, S - 1)) * ld + a.H + h * HD;
-    store_tile16x64<T>(outk, dk_, 1.0f, g, key < S);
-    store_tile16x64<T>(outk + a.H, dv_, 1.0f, g, key < S);
+    store_tile16x64<T>(outk, dk_, 1.0f, g, key < S && !PDT_ATT_NOSTORE);
+    store_tile16x64<T>(outk + a.H, dv_, 1.0f, g, key < S && !PDT_ATT_NOSTORE);
   }
   PDT_STAMP(5);
   if (dbias) {
