@@ -152,10 +152,11 @@ int pdt_dropout_apply(int dtype, const void* x, void* y, int64_t n, int H, float
 // longest sequence, mask and kv_len are not read.
 int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu, void* ctx,
                  float* lse, int B, int S, int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);
-// dqkv 16-bit [B*S, 3H];  delta fp32 [B,A,S] scratch.  dbias (nullable, fp32 [B][3H]): per-sample column sums of
-// dqkv (finish with pdt_colsum_finish(dbias, B, 3H, 1, ...) to get the QKV bias gradient) - only available
-// when pdt_attn_bwd_fuses_dbias(S) is 1, otherwise pass null and reduce dqkv separately.
+// dqkv 16-bit [B*S, 3H];  delta fp32 [B,A,S] scratch.  dbias (nullable, fp32 [rows][3H] with rows =
+// pdt_attn_bwd_dbias_rows(B, S), one per sample and 128-row block): partial column sums of dqkv (finish with
+// pdt_colsum_finish(dbias, rows, 3H, 1, ...) to get the QKV bias gradient).
 int pdt_attn_bwd_fuses_dbias(int S);
+int pdt_attn_bwd_dbias_rows(int B, int S);
 int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu,
                  const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias, int B, int S,
                  int A, float drop_scale, uint32_t drop_thr, PdtRng rng, void* stream);

@@ -260,11 +260,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   store_tile16x64<T>((T*)a.ctx + ((size_t)row0 + qc) * a.H + h * HD, o, inv, g, q < S);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x128>(v);  // row_ror:8
+  v += dpp_f<0x124>(v);  // row_ror:4
+  v += dpp_f<0x122>(v);  // row_ror:2
+  v += dpp_f<0x121>(v);  // row_ror:1
+  return v;
+}
 // ------------------------------------------------------------------------------------------------ dQ (S > 128)
 // One wave = 16 query rows, sweeps the keys chunk by chunk; also produces delta = rowsum(dO * O) for the
 // dK/dV kernel.  Log2-domain recomputation with the softmax scale folded into the exponent.
+// dbias (nullable): fp32 [B * gridDim.y][3H] - this workgroup's column sums of dQ go to row b * gridDim.y + blockIdx.y,
+// columns h*64.. (the dK/dV kernel fills the other two thirds of the same rows; pdt_colsum_finish adds the rows up)
 template <typename T>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = smem + ATT_CHUNK * 128;
@@ -345,13 +359,34 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     }
   }
   if (active) store_tile16x64<T>((T*)a.dqkv + ((size_t)row0 + qc) * ld + h * HD, dq, 1.0f, g, q < S);
+  if (dbias) {  // rows >= S of an active wave are exactly zero (lse = +inf)
+    float* csq = mbias + ATT_SMAX;  // [ATT_WAVES][64]
+    if (active) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        float4v t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = row16_sum(dq[db][r]);
+        if (lm == 0) *reinterpret_cast<float4v*>(csq + wave * 64 + db * 16 + 4 * g) = t;
+      }
+    } else {
+      csq[wave * 64 + lane] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < ATT_WAVES; ++w) t += csq[w * 64 + tid];
+      dbias[((size_t)b * gridDim.y + blockIdx.y) * 3 * a.H + h * HD + tid] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV (S > 128)
 // One wave = 16 keys, sweeps the queries chunk by chunk (Q and dO images); per-row lse / delta / dropout seeds
 // of the whole sequence are staged in LDS once.
 template <typename T>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
   char* dimg = smem + ATT_CHUNK * 128;
@@ -443,6 +478,27 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
     store_tile16x64<T>(outk, dk_, 1.0f, g, key < S);
     store_tile16x64<T>(outk + a.H, dv_, 1.0f, g, key < S);
   }
+  if (dbias) {  // rows of keys >= S or >= kv_len are exactly zero in dk_ / dv_ (also those of an inactive wave)
+    float* cskv = reinterpret_cast<float*>(seed_s + ATT_SMAX);  // [ATT_WAVES][128] dK | dV
+    __syncthreads();  // (every wave has left the sweep before the staging area behind its scalars is reused)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      float4v tk, tv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { tk[r] = row16_sum(dk_[db][r]); tv[r] = row16_sum(dv_[db][r]); }
+      if (lm == 0) {
+        *reinterpret_cast<float4v*>(cskv + wave * 128 + db * 16 + 4 * g) = tk;
+        *reinterpret_cast<float4v*>(cskv + wave * 128 + 64 + db * 16 + 4 * g) = tv;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < ATT_WAVES; ++w) t += cskv[w * 128 + tid];
+      dbias[((size_t)b * gridDim.y + blockIdx.y) * 3 * a.H + (1 + (tid >> 6)) * a.H + h * HD + (tid & 63)] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward, S <= 128
@@ -452,18 +508,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a) {
 // never leaves LDS, and the column sums of dQ/dK/dV (the QKV bias gradient) are reduced here without atomics:
 // DPP row reductions over the 16 rows of a wave, one LDS slot per wave, then the workgroup writes its 192
 // sums to dbias_partial[b][3H] (summed over b afterwards by the deterministic column-sum finisher).
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); every lane of the row receives the total
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_f<0x128>(v);  // row_ror:8
-  v += dpp_f<0x124>(v);  // row_ror:4
-  v += dpp_f<0x122>(v);  // row_ror:2
-  v += dpp_f<0x121>(v);  // row_ror:1
-  return v;
-}
 // bench/micro/attn_stamp.hip builds this file with PDT_ATT_NOCOMPUTE=1 (both sweeps of the fused backward compiled out:
 // what is left is its memory traffic) and / or PDT_ATT_NOSTORE=1 (dQ / dK / dV are not written)
 #ifndef PDT_ATT_NOCOMPUTE
@@ -718,21 +762,21 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
 #undef PDT_STAMP
 }
 
-template <typename KernT>
-static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t stream) {
-  hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a);
+template <typename KernT, typename... Extra>
+static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t stream, Extra... extra) {
+  hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a, extra...);
   return (int)hipGetLastError();
 }
 
 // which: 0 forward, 1 dQ, 2 dK/dV
 template <typename T>
-static int attn_dispatch(int which, const AttnArgs& a, hipStream_t s) {
+static int attn_dispatch(int which, const AttnArgs& a, float* dbias, hipStream_t s) {
   const size_t imgs = (size_t)2 * ATT_CHUNK * 128;
   if (which == 0)
     return a.drop_thr != 0 ? launch_attn(attn_fwd_kernel<T, true>, a, imgs + ATT_SMAX * sizeof(float), s)
                            : launch_attn(attn_fwd_kernel<T, false>, a, imgs + ATT_SMAX * sizeof(float), s);
-  if (which == 1) return launch_attn(attn_bwd_dq_kernel<T>, a, imgs + ATT_SMAX * sizeof(float), s);
-  return launch_attn(attn_bwd_dkv_kernel<T>, a, imgs + 3 * ATT_SMAX * sizeof(float), s);
+  if (which == 1) return launch_attn(attn_bwd_dq_kernel<T>, a, imgs + (ATT_SMAX + ATT_WAVES * 64) * sizeof(float), s, dbias);
+  return launch_attn(attn_bwd_dkv_kernel<T>, a, imgs + (3 * ATT_SMAX + ATT_WAVES * 128) * sizeof(float), s, dbias);
 }
 
 }  // namespace pdt
@@ -750,7 +794,8 @@ extern "C" int pdt_attn_fwd(int dtype, const void* qkv, const int32_t* mask, con
   a.qkv = qkv; a.mask = mask; a.kv_len = kv_len; a.cu = cu; a.ctx = ctx; a.lse = lse;
   a.B = B; a.S = S; a.A = A; a.H = A * HD; a.scale = ATT_SCALE;
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
-  return dtype == PDT_F16 ? attn_dispatch<_Float16>(0, a, (hipStream_t)stream) : attn_dispatch<__bf16>(0, a, (hipStream_t)stream);
+  return dtype == PDT_F16 ? attn_dispatch<_Float16>(0, a, nullptr, (hipStream_t)stream)
+                          : attn_dispatch<__bf16>(0, a, nullptr, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -768,7 +813,8 @@ static int launch_fused128(const AttnArgs& a, float* dbias, hipStream_t stream) 
   return (int)hipGetLastError();
 }
 
-extern "C" int pdt_attn_bwd_fuses_dbias(int S) { return S <= 128 ? 1 : 0; }
+extern "C" int pdt_attn_bwd_fuses_dbias(int S) { return S <= ATT_SMAX ? 1 : 0; }
+extern "C" int pdt_attn_bwd_dbias_rows(int B, int S) { return B * ((S + ATT_ROWS - 1) / ATT_ROWS); }
 
 extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, const int32_t* kv_len, const int32_t* cu,
                             const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv, float* dbias,
@@ -783,7 +829,7 @@ extern "C" int pdt_attn_bwd(int dtype, const void* qkv, const int32_t* mask, con
   a.drop_scale = drop_scale; a.drop_thr = drop_thr; a.rng = rng;
   hipStream_t s = (hipStream_t)stream;
   if (S <= 128) return dtype == PDT_F16 ? launch_fused128<_Float16>(a, dbias, s) : launch_fused128<__bf16>(a, dbias, s);
-  int e = dtype == PDT_F16 ? attn_dispatch<_Float16>(1, a, s) : attn_dispatch<__bf16>(1, a, s);
+  int e = dtype == PDT_F16 ? attn_dispatch<_Float16>(1, a, dbias, s) : attn_dispatch<__bf16>(1, a, dbias, s);
   if (e) return e;
-  return dtype == PDT_F16 ? attn_dispatch<_Float16>(2, a, s) : attn_dispatch<__bf16>(2, a, s);
+  return dtype == PDT_F16 ? attn_dispatch<_Float16>(2, a, dbias, s) : attn_dispatch<__bf16>(2, a, dbias, s);
 }

@@ -402,14 +402,15 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   Tensor delta = at::empty_like(lse);
   // the short-sequence backward kernel also emits per-sample column sums of dqkv (the QKV bias gradient)
   const bool fused_db = pdt_attn_bwd_fuses_dbias((int)S) != 0;
-  Tensor db_part = fused_db ? at::empty({B, 3 * (int64_t)H}, lse.options()) : Tensor();
+  const int db_rows = pdt_attn_bwd_dbias_rows((int)B, (int)S);
+  Tensor db_part = fused_db ? at::empty({(int64_t)db_rows, 3 * (int64_t)H}, lse.options()) : Tensor();
   check(pdt_attn_bwd(dt_code(x), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(), cup, ctx.data_ptr(),
                      dctx.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
                      fused_db ? db_part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p_attn),
                      thr16(p_attn), make_rng(rng_state, micro, site + 0, sids, S, B), cur_stream()),
         "attn_bwd");
   if (fused_db)
-    fq.add(db_part, (int)B, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, accumulate);
+    fq.add(db_part, db_rows, 3 * H, 1, gr[1].data_ptr<float>(), nullptr, nullptr, accumulate);
   else
     colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
@@ -678,14 +679,15 @@ Tensor op_attn_bwd(const Tensor& qkv, const Tensor& mask, const Tensor& kv_len, 
   // `dbias` (fp32 [3H]): the column sums of dqkv are added to it (short-sequence kernel only)
   const int64_t H3 = qkv.size(1);
   Tensor part;
-  if (dbias.has_value()) { chkf32(*dbias, "dbias"); part = at::empty({B, H3}, lse.options()); }
+  const int db_rows = pdt_attn_bwd_dbias_rows((int)B, (int)S);
+  if (dbias.has_value()) { chkf32(*dbias, "dbias"); part = at::empty({(int64_t)db_rows, H3}, lse.options()); }
   check(pdt_attn_bwd(dt_code(qkv), qkv.data_ptr(), mask.data_ptr<int32_t>(), kv_len.data_ptr<int32_t>(),
                      cu.has_value() ? cu->data_ptr<int32_t>() : nullptr, ctx.data_ptr(),
                      dc.data_ptr(), lse.data_ptr<float>(), delta.data_ptr<float>(), dqkv.data_ptr(),
                      dbias.has_value() ? part.data_ptr<float>() : nullptr, (int)B, (int)S, (int)A, keep_scale(p),
                      thr16(p), rng, cur_stream()), "attn_bwd");
   if (dbias.has_value())
-    check(pdt_colsum_finish(part.data_ptr<float>(), (int)B, (int)H3, 1, dbias->data_ptr<float>(), nullptr, nullptr, nullptr, 1,
+    check(pdt_colsum_finish(part.data_ptr<float>(), db_rows, (int)H3, 1, dbias->data_ptr<float>(), nullptr, nullptr, nullptr, 1,
                             cur_stream()), "colsum_finish");
   return dqkv;
 }
