@@ -10,7 +10,9 @@
 // of the next MFMA (16x16x32, k index permuted consistently on both operands), and the other operand is
 // fetched from a row-major LDS image with ds_read_b64_tr_b16.  One XOR-swizzled image layout
 // (16-B chunk ^= row & 6) is conflict-free for both the ds_read_b128 row reads and the transposed reads.
+#include <mutex>
 #include <type_traits>
+#include <unordered_set>
 
 #include "common.hpp"
 
@@ -158,6 +160,24 @@ __device__ __forceinline__ void store_tile16x64(T* row, const float4v (&t)[4], f
 // head dim 64), so what they need is waves to interleave, not a resident K/V panel.
 constexpr int ATT_SMAX = 512;   // longest sequence
 constexpr int ATT_CHUNK = 128;  // rows per LDS image
+// Two image PAIRS (K | V, or Q | dO): the chunk loops are double-buffered - chunk c+1 is staged while chunk c is worked
+// on.  (With one pair every chunk began with an exposed fill; at seq 512, four chunks per workgroup, the three kernels
+// spent half their wave-cycles waiting.)
+constexpr int ATT_IMG_BYTES = 4 * ATT_CHUNK * 128;
+// Top of a chunk-loop iteration (`stage(c0, buf)` in scope; each wave issues 4 DMA pieces per chunk): every wave is done
+// with the chunk before, so its pair may be refilled with the chunk after this one; then this chunk has landed for
+// every wave (all but the 4 newest pieces of this wave, then the barrier).
+#define PDT_ATT_NEXT_CHUNK(C0, BUF, END)                                              \
+  do {                                                                                \
+    if (C0) __syncthreads();                                                          \
+    if ((C0) + ATT_CHUNK < (END)) {                                                   \
+      stage((C0) + ATT_CHUNK, (BUF) ^ 1);                                             \
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                \
+    } else {                                                                          \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    }                                                                                 \
+    __syncthreads();                                                                  \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------ forward
 // One wave = 16 query rows.  Online softmax over the key chunks in the log2 domain: running maximum m, running
@@ -166,9 +186,7 @@ constexpr int ATT_CHUNK = 128;  // rows per LDS image
 template <typename T, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kimg = smem;
-  char* vimg = smem + ATT_CHUNK * 128;
-  float* mbias = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  float* mbias = reinterpret_cast<float*>(smem + ATT_IMG_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
@@ -178,6 +196,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const T* base = (const T*)a.qkv + (size_t)row0 * ld + h * HD;
   const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int npb = (kvl + 31) >> 5;
+  // chunk c0 of the keys and values into image pair `buf` (4 LDS-DMA pieces per wave)
+  auto stage = [&](int c0, int buf) {
+    char* kb = smem + buf * (2 * ATT_CHUNK * 128);
+    dma_image128<T>(kb, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    dma_image128<T>(kb + ATT_CHUNK * 128, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+  };
+  if (npb > 0) stage(0, 0);
   for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && (a.cu || a.mask[(size_t)b * SM + k] != 0)) ? 0.f : -INFINITY;
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
@@ -194,12 +219,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   float4v o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < npb * 32; c0 += ATT_CHUNK) {
-    if (c0) __syncthreads();  // every wave is done with the previous chunk
-    dma_image128<T>(kimg, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
-    dma_image128<T>(vimg, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  for (int c0 = 0, buf = 0; c0 < npb * 32; c0 += ATT_CHUNK, buf ^= 1) {
+    PDT_ATT_NEXT_CHUNK(c0, buf, npb * 32);
+    const char* kimg = smem + buf * (2 * ATT_CHUNK * 128);
+    const char* vimg = kimg + ATT_CHUNK * 128;
     if (!active) continue;
     const int nb = min(ATT_CHUNK / 32, npb - (c0 >> 5));  // 32-key blocks in this chunk
     // The body exists twice: for a full chunk (four 32-key blocks: every sequence of the fixed-length benchmark
@@ -280,9 +303,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <typename T>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kimg = smem;
-  char* vimg = smem + ATT_CHUNK * 128;
-  float* mbias = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  float* mbias = reinterpret_cast<float*>(smem + ATT_IMG_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
@@ -294,6 +315,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, fl
   const T* ob = (const T*)a.octx + (size_t)row0 * a.H + h * HD;
   const int kvl = (a.cu ? S : min(a.kv_len[b], S));
   const int npb = (kvl + 31) >> 5;
+  auto stage = [&](int c0, int buf) {
+    char* kb = smem + buf * (2 * ATT_CHUNK * 128);
+    dma_image128<T>(kb, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+    dma_image128<T>(kb + ATT_CHUNK * 128, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
+  };
+  if (npb > 0) stage(0, 0);
   for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && (a.cu || a.mask[(size_t)b * SM + k] != 0)) ? 0.f : -INFINITY;
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
@@ -322,12 +349,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, fl
   float4v dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < npb * 32; c0 += ATT_CHUNK) {
-    if (c0) __syncthreads();
-    dma_image128<T>(kimg, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
-    dma_image128<T>(vimg, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  for (int c0 = 0, buf = 0; c0 < npb * 32; c0 += ATT_CHUNK, buf ^= 1) {
+    PDT_ATT_NEXT_CHUNK(c0, buf, npb * 32);
+    const char* kimg = smem + buf * (2 * ATT_CHUNK * 128);
+    const char* vimg = kimg + ATT_CHUNK * 128;
     if (!active) continue;
     const int nb = min(ATT_CHUNK / 32, npb - (c0 >> 5));
 #pragma unroll
@@ -388,9 +413,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, fl
 template <typename T>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* qimg = smem;
-  char* dimg = smem + ATT_CHUNK * 128;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * ATT_CHUNK * 128);
+  float* lse_s = reinterpret_cast<float*>(smem + ATT_IMG_BYTES);
   float* del_s = lse_s + ATT_SMAX;
   uint32_t* seed_s = reinterpret_cast<uint32_t*>(del_s + ATT_SMAX);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -426,12 +449,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, f
     const uint32_t kmul = (uint32_t)key * ATT_GOLD, thr_hi = attn_thr_hi(a.drop_thr);
     const float k2 = a.scale * LOG2E, dsc2 = a.drop_scale * a.scale;
     const bool drop = a.drop_thr != 0;
-    for (int c0 = 0; c0 < nqb * 32; c0 += ATT_CHUNK) {
-      if (c0) __syncthreads();
-      dma_image128<T>(qimg, base + (size_t)c0 * ld, ld, S - c0, tid, wave);
-      dma_image128<T>(dimg, dob + (size_t)c0 * a.H, a.H, S - c0, tid, wave);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // also orders the lse / delta / seed staging before its first use
+    // chunk c0 of the queries and of dO into image pair `buf`
+    auto stage = [&](int c0, int buf) {
+      char* qb = smem + buf * (2 * ATT_CHUNK * 128);
+      dma_image128<T>(qb, base + (size_t)c0 * ld, ld, S - c0, tid, wave);
+      dma_image128<T>(qb + ATT_CHUNK * 128, dob + (size_t)c0 * a.H, a.H, S - c0, tid, wave);
+    };
+    if (nqb > 0) stage(0, 0);
+    for (int c0 = 0, buf = 0; c0 < nqb * 32; c0 += ATT_CHUNK, buf ^= 1) {
+      PDT_ATT_NEXT_CHUNK(c0, buf, nqb * 32);  // (its barrier also orders the lse / delta / seed staging before its first use)
+      const char* qimg = smem + buf * (2 * ATT_CHUNK * 128);
+      const char* dimg = qimg + ATT_CHUNK * 128;
       if (!wave_active) continue;
       const int nb = min(ATT_CHUNK / 32, nqb - (c0 >> 5));
 #pragma unroll
@@ -762,8 +790,22 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
 #undef PDT_STAMP
 }
 
+// more than 64 KiB of dynamic LDS needs the attribute; set once per kernel (not a stream operation: done at the first
+// launch, i.e. in the warm-up of a step that is later captured into a graph)
+static int allow_big_lds(const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::unordered_set<const void*> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(kern)) return 0;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  done.insert(kern);
+  return 0;
+}
+
 template <typename KernT, typename... Extra>
 static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t stream, Extra... extra) {
+  if (int e = allow_big_lds((const void*)kern, lds)) return e;
   hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a, extra...);
   return (int)hipGetLastError();
 }
@@ -771,7 +813,7 @@ static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t st
 // which: 0 forward, 1 dQ, 2 dK/dV
 template <typename T>
 static int attn_dispatch(int which, const AttnArgs& a, float* dbias, hipStream_t s) {
-  const size_t imgs = (size_t)2 * ATT_CHUNK * 128;
+  const size_t imgs = (size_t)ATT_IMG_BYTES;
   if (which == 0)
     return a.drop_thr != 0 ? launch_attn(attn_fwd_kernel<T, true>, a, imgs + ATT_SMAX * sizeof(float), s)
                            : launch_attn(attn_fwd_kernel<T, false>, a, imgs + ATT_SMAX * sizeof(float), s);
