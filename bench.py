@@ -43,7 +43,9 @@ from pytorch_distributed_training_amd.models.bert import build_model  # noqa: E4
 from pytorch_distributed_training_amd.optim import AdamW, get_linear_schedule_with_warmup  # noqa: E402
 
 
-REFERENCE_STACK_1GPU = 2014.0  # samples/s, bert-large-cased, seq 128, batch 1024, fp16 AMP, one MI355X
+# samples/s of the reference's software stack (transformers + torch AMP, SDPA attention) on one MI355X: bert-large-cased,
+# seq 128, batch 1024, fp16 - bench/eager_baseline.py; 2014 / 2018 / 1993 in three table runs (profiles/perf_table_*.jsonl)
+REFERENCE_STACK_1GPU = 2014.0
 
 
 def main() -> None:
@@ -193,8 +195,7 @@ def main() -> None:
             "rccl_ranks": model.rccl_ranks() if hasattr(model, "rccl_ranks") else 0,
             "replicas_bit_equal": replicas_equal,
             # not a published number (the reference has none, hence vs_baseline = null): the reference's software
-            # stack (transformers + torch AMP, SDPA attention) measured on one MI355X at this configuration with
-            # bench/eager_baseline.py (last lines of profiles/perf_table_mi355x.jsonl: 2014 and 2018 samples/s in two runs)
+            # stack measured on the same kind of GPU at this configuration (REFERENCE_STACK_1GPU above)
             "vs_reference_stack_1gpu": (round(value / REFERENCE_STACK_1GPU, 3)
                                         if (world == 1 and args.model == "bert-large-cased" and args.seq_len == 128
                                             and args.batch == 1024) else None),
@@ -338,14 +339,6 @@ def _persist_mode() -> int:
 def _pretty(model: str) -> str:
     return {"bert-large-cased": "BERT-large", "bert-base-cased": "BERT-base", "roberta-large": "RoBERTa-large",
             "roberta-base": "RoBERTa-base"}.get(model, model)
-
-
-class _null:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
 
 
 def _fence(eng: Engine) -> None:
