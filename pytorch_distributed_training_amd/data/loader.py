@@ -7,7 +7,7 @@ Batches are pinned and copied on a side HIP stream one step ahead of the consume
 """
 from __future__ import annotations
 
-from typing import Iterator, Optional
+from typing import Iterator
 
 import torch
 from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler

@@ -13,7 +13,7 @@
 from __future__ import annotations
 
 import math
-from typing import Iterator, List, Optional
+from typing import Iterator, List
 
 import torch
 from torch.utils.data import Sampler

@@ -27,7 +27,6 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .bert import SequenceClassifierOutput, build_model
 
@@ -246,7 +245,6 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
 
 def run_tower_training(rank: int, world_size: int, cfg) -> dict:
     """TriBert training with the towers spread over rank pairs, data parallel across pairs."""
-    from torch.utils.data import DataLoader
 
     from .. import checkpoint as ckpt
     from .. import launch

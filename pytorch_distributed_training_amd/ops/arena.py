@@ -16,7 +16,7 @@ address order == the order in which backward finishes gradients == bucket launch
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch

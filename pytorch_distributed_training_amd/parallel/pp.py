@@ -206,7 +206,6 @@ class PipelineStage:
 # ---------------------------------------------------------------------------------------------------------
 def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     """DP x 2-stage-MP training recipe (see recipes.run_model_parallel)."""
-    from torch.utils.data import DataLoader
 
     from .. import checkpoint as ckpt
     from ..engine import Engine

@@ -23,7 +23,7 @@ all-reduces are issued through c10d, which owns its own stream and work objects)
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Optional
 
 import torch
 

@@ -5,7 +5,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 

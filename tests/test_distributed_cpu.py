@@ -2,8 +2,6 @@
 import os
 import sys
 
-import pytest
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dist_workers as W  # noqa: E402

@@ -4,7 +4,6 @@ import os
 
 import pytest
 import torch
-import torch.nn.functional as F
 
 import pytorch_distributed_training_amd as pdt  # noqa: F401
 from pytorch_distributed_training_amd.config import TrainConfig, parse_config, str2bool

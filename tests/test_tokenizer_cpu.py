@@ -1,5 +1,4 @@
 """C++ WordPiece against transformers' BertTokenizer on a locally written vocabulary, and the local MRPC reader."""
-import os
 
 import pytest
 
