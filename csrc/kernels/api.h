@@ -169,11 +169,13 @@ int pdt_head_fwd(int dtype, const void* pooled, const float* W, const float* bia
                  void* stream);
 // gloss[0] = upstream gradient of the mean loss (null: no CE term); dlogits_in [B,C] = explicit upstream
 // gradient of the logits (null: none).  dpooled 16-bit [B,H] (times 1-pooled^2 when tanh_bwd);
-// dW [C,H], dbias [C] fp32 (+= when accumulate)
+// dW [C,H], dbias [C] fp32 (+= when accumulate).  ws: fp32 workspace of pdt_head_bwd_ws_floats(B, H, C) elements (0 for
+// small batches: then ws may be null) - larger batches are cut into slices whose shares a finishing launch adds up.
+int64_t pdt_head_bwd_ws_floats(int B, int H, int C);
 int pdt_head_bwd(int dtype, const void* pooled, const float* W, const float* logits, const int64_t* labels,
                  const float* gloss, const float* dlogits_in, void* dpooled, float* dW, float* dbias, int B, int H,
                  int C, float drop_scale,
-                 uint32_t drop_thr, PdtRng rng, int accumulate, int tanh_bwd, void* stream);
+                 uint32_t drop_thr, PdtRng rng, int accumulate, int tanh_bwd, float* ws, void* stream);
 
 // ---- Optimizer ----------------------------------------------------------------------------------------
 typedef struct PdtAdamW {

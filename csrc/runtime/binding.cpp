@@ -551,11 +551,13 @@ Tensor head_backward(const c10::optional<Tensor>& gloss, const c10::optional<Ten
   if (ce) gl = gloss->to(at::kFloat).contiguous();
   if (dlogits.has_value()) dl = dlogits->to(at::kFloat).contiguous();
   Tensor dpooled = at::empty_like(pooled);
+  const int64_t ws_n = pdt_head_bwd_ws_floats(B, H, C);
+  Tensor ws = ws_n > 0 ? at::empty({ws_n}, gW.options()) : Tensor();
   check(pdt_head_bwd(dt_code(pooled), pooled.data_ptr(), W.data_ptr<float>(), logits.data_ptr<float>(),
                      ce ? labels->data_ptr<int64_t>() : nullptr, ce ? gl.data_ptr<float>() : nullptr,
                      dl.defined() ? dl.data_ptr<float>() : nullptr, dpooled.data_ptr(), gW.data_ptr<float>(),
                      gb.data_ptr<float>(), B, H, C, keep_scale(p), thr16(p), make_rng(rng_state, micro, site, sids, 1, B),
-                     accumulate ? 1 : 0, tanh_bwd ? 1 : 0, cur_stream()), "head_bwd");
+                     accumulate ? 1 : 0, tanh_bwd ? 1 : 0, ws_n > 0 ? ws.data_ptr<float>() : nullptr, cur_stream()), "head_bwd");
   return dpooled;
 }
 

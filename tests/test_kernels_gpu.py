@@ -414,10 +414,13 @@ def test_embedding_table_gradients_are_a_deterministic_segmented_sum():
     assert rel_err(g1[0], 2 * want_w) < 1e-5 and rel_err(g1[1], 2 * want_p) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-def test_head_fwd_bwd(dtype):
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B", [37, 64, 65, 300, 1024])
+def test_head_fwd_bwd(dtype, B):
+    """B <= 64: one workgroup per direction; beyond, the logits are computed in parallel over 64-sample slices, the loss
+    by one workgroup from the logits, and the backward's per-slice shares of dW / dbias are summed by a finishing launch."""
     torch.manual_seed(8)
-    B, H, Cn = 37, 256, 2
+    H, Cn = 256, 2
     pooled = torch.tanh(torch.randn(B, H, device="cuda")).to(dtype)
     W = torch.randn(Cn, H, device="cuda") * 0.1
     bias = torch.randn(Cn, device="cuda") * 0.1
@@ -436,6 +439,26 @@ def test_head_fwd_bwd(dtype):
     assert rel_err(dp, pf.grad) < 1e-2
     assert rel_err(gW, Wf.grad) < 1e-4
     assert rel_err(gb, bf.grad) < 1e-4
+    # accumulate = True adds to what is there; two runs are bit-identical (fixed summation order)
+    gW2, gb2 = gW.clone(), gb.clone()
+    C().head_backward(torch.tensor(3.0, device="cuda"), None, pooled, W, logits, labels, gW2, gb2, st, 0.0, 0, 0, True, False, None)
+    assert rel_err(gW2, 2 * Wf.grad) < 1e-4 and rel_err(gb2, 2 * bf.grad) < 1e-4
+    gW3, gb3 = torch.zeros_like(W), torch.zeros_like(bias)
+    C().head_backward(torch.tensor(3.0, device="cuda"), None, pooled, W, logits, labels, gW3, gb3, st, 0.0, 0, 0, False, False, None)
+    assert torch.equal(gW3, gW) and torch.equal(gb3, gb)
+    # dropout: forward and backward draw the same mask (recovered from the gradient wrt the pooled input of an explicit
+    # O(1) upstream gradient of the logits - nothing that could underflow in 16 bits)
+    lg, _ = C().head_forward(pooled, W, bias, labels, st, 0.25, 3, 7, None)
+    gW4, gb4 = torch.zeros_like(W), torch.zeros_like(bias)
+    dl = torch.zeros(B, Cn, device="cuda")
+    dl[:, 0] = 1.0 + torch.rand(B, device="cuda")    # one class only: dl @ W cannot cancel
+    dpd = C().head_backward(None, dl, pooled, W, lg, None, gW4, gb4, st, 0.25, 3, 7, False, False, None)
+    full = dl @ W                                    # gradient without the mask; times 1/(1-p) where kept
+    keep = (dpd.float().abs() > 0) | (full.abs() < 1e-6)
+    assert 0.70 < keep.float().mean().item() < 0.80
+    xd = pooled.float() * keep / 0.75
+    torch.testing.assert_close(lg, F.linear(xd, W, bias), rtol=5e-3, atol=5e-3)
+    assert rel_err(gW4, dl.t() @ xd) < 2e-3 and rel_err(gb4, dl.sum(0)) < 1e-4
 
 
 def test_adamw_matches_hf_formula_and_skips_on_overflow():
