@@ -183,10 +183,13 @@ constexpr int ATT_IMG_BYTES = 4 * ATT_CHUNK * 128;
 // One wave = 16 query rows.  Online softmax over the key chunks in the log2 domain: running maximum m, running
 // sum l (per lane, reduced once at the end), output accumulators rescaled by exp2(m_old - m_new) per chunk.
 // Dropout multiplies the un-normalised probabilities (the 1/l factor is applied to the output at the end).
-template <typename T, bool DROP>
+// DBUF: two image pairs, chunk c+1 staged under chunk c (sequences of more than one chunk); without it one pair,
+// filled at the top of every chunk (the single-chunk launch: nothing to stage ahead, and the simpler loop measured
+// 10 % faster there)
+template <typename T, bool DROP, bool DBUF>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* mbias = reinterpret_cast<float*>(smem + ATT_IMG_BYTES);
+  float* mbias = reinterpret_cast<float*>(smem + (DBUF ? ATT_IMG_BYTES : ATT_IMG_BYTES / 2));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x, b = bh / a.A, h = bh % a.A;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     dma_image128<T>(kb, base + a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
     dma_image128<T>(kb + ATT_CHUNK * 128, base + 2 * a.H + (size_t)c0 * ld, ld, S - c0, tid, wave);
   };
-  if (npb > 0) stage(0, 0);
+  if (DBUF && npb > 0) stage(0, 0);
   for (int k = tid; k < npb * 32; k += ATT_THREADS) mbias[k] = (k < S && (a.cu || a.mask[(size_t)b * SM + k] != 0)) ? 0.f : -INFINITY;
 
   const int q0 = blockIdx.y * ATT_ROWS + wave * 16;
@@ -219,8 +222,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   float4v o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0, buf = 0; c0 < npb * 32; c0 += ATT_CHUNK, buf ^= 1) {
-    PDT_ATT_NEXT_CHUNK(c0, buf, npb * 32);
+  for (int c0 = 0, buf = 0; c0 < npb * 32; c0 += ATT_CHUNK, buf ^= (DBUF ? 1 : 0)) {
+    if (DBUF) {
+      PDT_ATT_NEXT_CHUNK(c0, buf, npb * 32);
+    } else {
+      if (c0) __syncthreads();  // every wave is done with the previous chunk
+      stage(c0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     const char* kimg = smem + buf * (2 * ATT_CHUNK * 128);
     const char* vimg = kimg + ATT_CHUNK * 128;
     if (!active) continue;
@@ -792,12 +802,13 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
 
 // more than 64 KiB of dynamic LDS needs the attribute; set once per kernel (not a stream operation: done at the first
 // launch, i.e. in the warm-up of a step that is later captured into a graph)
-static int allow_big_lds(const void* kern, size_t lds) {
+static int allow_big_lds(const void* kern) {
   static std::mutex mu;
   static std::unordered_set<const void*> done;
   std::lock_guard<std::mutex> lock(mu);
   if (done.count(kern)) return 0;
-  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // (the largest footprint any launch of these kernels asks for: two image pairs + scalars + column-sum staging)
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return (int)e;
   done.insert(kern);
   return 0;
@@ -805,7 +816,8 @@ static int allow_big_lds(const void* kern, size_t lds) {
 
 template <typename KernT, typename... Extra>
 static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t stream, Extra... extra) {
-  if (int e = allow_big_lds((const void*)kern, lds)) return e;
+  if (lds > 80 * 1024) return -3;
+  if (int e = allow_big_lds((const void*)kern)) return e;
   hipLaunchKernelGGL(kern, dim3(a.B * a.A, (a.S + ATT_ROWS - 1) / ATT_ROWS), dim3(ATT_THREADS), lds, stream, a, extra...);
   return (int)hipGetLastError();
 }
@@ -814,9 +826,15 @@ static int launch_attn(KernT kern, const AttnArgs& a, size_t lds, hipStream_t st
 template <typename T>
 static int attn_dispatch(int which, const AttnArgs& a, float* dbias, hipStream_t s) {
   const size_t imgs = (size_t)ATT_IMG_BYTES;
-  if (which == 0)
-    return a.drop_thr != 0 ? launch_attn(attn_fwd_kernel<T, true>, a, imgs + ATT_SMAX * sizeof(float), s)
-                           : launch_attn(attn_fwd_kernel<T, false>, a, imgs + ATT_SMAX * sizeof(float), s);
+  if (which == 0) {
+    const bool drop = a.drop_thr != 0;
+    if (a.S > ATT_CHUNK) {
+      const size_t lds = imgs + ATT_SMAX * sizeof(float);
+      return drop ? launch_attn(attn_fwd_kernel<T, true, true>, a, lds, s) : launch_attn(attn_fwd_kernel<T, false, true>, a, lds, s);
+    }
+    const size_t lds = imgs / 2 + ATT_SMAX * sizeof(float);
+    return drop ? launch_attn(attn_fwd_kernel<T, true, false>, a, lds, s) : launch_attn(attn_fwd_kernel<T, false, false>, a, lds, s);
+  }
   if (which == 1) return launch_attn(attn_bwd_dq_kernel<T>, a, imgs + (ATT_SMAX + ATT_WAVES * 64) * sizeof(float), s, dbias);
   return launch_attn(attn_bwd_dkv_kernel<T>, a, imgs + (3 * ATT_SMAX + ATT_WAVES * 128) * sizeof(float), s, dbias);
 }
