@@ -18,13 +18,19 @@ import sys
 from collections import defaultdict
 
 
+def key_of(r):
+    """A call site: kernel name + grid size (tells the GEMM shapes of one kernel apart when they are launched with one
+    workgroup per tile)."""
+    return r["Kernel_Name"], int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+
+
 def counters(path, name):
     f = glob.glob(path + "/**/*_counter_collection.csv", recursive=True)[0]
     tot, calls = defaultdict(float), defaultdict(set)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
-            tot[r["Kernel_Name"]] += float(r["Counter_Value"])
-            calls[r["Kernel_Name"]].add(r["Dispatch_Id"])
+            tot[key_of(r)] += float(r["Counter_Value"])
+            calls[key_of(r)].add(r["Dispatch_Id"])
     return {k: tot[k] / max(1, len(calls[k])) for k in tot}
 
 
@@ -36,8 +42,8 @@ def main(fetch_dir, write_dir, trace, out=None):
     rd = {k: v * FETCH_SCALE for k, v in rd.items()}
     dur, n = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(trace)):
-        dur[r["Kernel_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-        n[r["Kernel_Name"]] += 1
+        dur[key_of(r)] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        n[key_of(r)] += 1
     rows = []
     for k in dur:
         if k in rd or k in wr:
@@ -47,9 +53,9 @@ def main(fetch_dir, write_dir, trace, out=None):
     rows.sort(reverse=True)
     lines = ["# HBM traffic per kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) + kernel trace durations",
              f"# (reads = FETCH_SIZE x {FETCH_SCALE:g}: the counter reports half the bytes of kernels with known traffic, see tools/hbm_summary.py)", "",
-             f"{'calls':>6} {'avg us':>9} {'GB read':>9} {'GB written':>11} {'TB/s':>6}  kernel"]
-    for _, k, c, us, r, w, rate in rows[:20]:
-        lines.append(f"{c:6d} {us:9.1f} {r:9.3f} {w:11.3f} {rate:6.2f}  {k.replace('pdt::', '')[:100]}")
+             f"{'calls':>6} {'avg us':>9} {'GB read':>9} {'GB written':>11} {'TB/s':>6} {'threads':>9}  kernel"]
+    for _, k, c, us, r, w, rate in rows[:24]:
+        lines.append(f"{c:6d} {us:9.1f} {r:9.3f} {w:11.3f} {rate:6.2f} {k[1]:9d}  {k[0].replace('pdt::', '')[:100]}")
     txt = "\n".join(lines)
     print(txt)
     if out:
