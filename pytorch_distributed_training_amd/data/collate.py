@@ -26,9 +26,10 @@ class BatchDict(dict):
 class PadCollator:
     def __init__(self, pad_token_id: int = 0, padding: str = "longest", max_length: Optional[int] = None,
                  pad_to_multiple_of: Optional[int] = None, varlen: bool = False):
-        """``varlen``: also emit ``cu_seqlens`` (int32 [B+1], first packed row of every sample) and ``token_index``
-        (int64 [T], the flat positions ``b * S + s`` of the real tokens): the native path then runs the encoder on
-        the T real tokens only - no GEMM row, LayerNorm row or attention key is spent on padding."""
+        """``varlen``: also emit ``cu_seqlens`` (int32 [B+1], first packed row of every sample), ``token_index``
+        (int64 [T], the flat positions ``b * S + s`` of the real tokens) and ``lengths`` (the per-sample token counts
+        as a host list): the native path then runs the encoder on the T real tokens only - no GEMM row, LayerNorm
+        row or attention key is spent on padding."""
         self.varlen = varlen
         if padding not in ("longest", "max_length"):
             raise ValueError("padding must be 'longest' or 'max_length'")
@@ -62,6 +63,7 @@ class PadCollator:
                 cu.append(cu[-1] + v)
             out["cu_seqlens"] = torch.as_tensor(cu, dtype=torch.int32)
             out["token_index"] = torch.cat([torch.arange(v, dtype=torch.long) + i * n for i, v in enumerate(lens)])
+            out["lengths"] = lens  # (a host list: stays on the host when the batch moves to the device)
         if "sample_ids" in examples[0]:  # global ids of the samples (data/loader.py adds them): sample-keyed dropout
             out["sample_ids"] = torch.as_tensor([e["sample_ids"] for e in examples], dtype=torch.int32)
         return out

@@ -369,33 +369,50 @@ class _ClassifierBase(nn.Module):
 
     # -- unpadded ("varlen") execution of the native path ----------------------------------------------------------
     def _can_run_unpadded(self, input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
-        return (cu_seqlens is not None and token_index is not None and self.runtime is not None and input_ids is not None
-                and input_ids.is_cuda and inputs_embeds is None and hidden_states is None and not output_hidden_states
-                and getattr(self, "with_head", False) and self.base_model.embeddings is not None)
+        if (cu_seqlens is None or token_index is None or self.runtime is None or inputs_embeds is not None
+                or output_hidden_states):
+            return False
+        if self.base_model.embeddings is not None:
+            return input_ids is not None and input_ids.is_cuda and hidden_states is None
+        # a later pipeline stage: its input is already the packed [T, H] block of the previous stage
+        return hidden_states is not None and hidden_states.is_cuda and hidden_states.dim() == 2
 
-    def _forward_unpadded(self, input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index):
-        """The whole model on the T real tokens of a dynamically padded batch (T = cu_seqlens[-1]): embeddings, every
-        GEMM, LayerNorm and attention work on packed [T, H] rows; the pooler reads the first row of every sample.
-        Numerically the padded computation restricted to the real tokens (padding never influences them); dropout
-        masks are keyed by (sample, position), so they are those of the padded run too.  ``last_hidden_state`` of
-        the result is the packed [T, H] tensor."""
+    def _forward_unpadded(self, input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index,
+                          hidden_states=None, padded_shape=None, inputs_embeds=None, run_head=True):
+        """The model (or one pipeline stage of it) on the T real tokens of a dynamically padded batch
+        (T = cu_seqlens[-1]): embeddings, every GEMM, LayerNorm and attention work on packed [T, H] rows; the pooler
+        reads the first row of every sample.  Numerically the padded computation restricted to the real tokens
+        (padding never influences them); dropout masks are keyed by (sample, position), so they are those of the
+        padded run too.  ``last_hidden_state`` of the result is the packed [T, H] tensor - the block a stage
+        without a head hands to the next one, which passes it back in as `hidden_states` together with the
+        `padded_shape` (B, S) of the batch it belongs to.  `inputs_embeds`: packed [T, H] word embeddings computed by
+        the caller instead of a lookup of `input_ids` (tower ensembles share one lookup); `run_head=False` stops
+        after the encoder stack."""
         from ..ops import fused
 
-        B, S = input_ids.shape
         base = self.base_model
         emb = base.embeddings
+        lookup = emb is not None and inputs_embeds is None
+        if not lookup and padded_shape is None:
+            raise ValueError("packed rows need the attention mask of their batch (for the padded shape)")
+        B, S = input_ids.shape if lookup else padded_shape
         tok = token_index
-        ids = input_ids.reshape(-1)[tok]
-        types = (token_type_ids.reshape(-1)[tok] if token_type_ids is not None else torch.zeros_like(ids))
-        pos = emb.position_ids(input_ids, B, S, input_ids.device).reshape(-1)[tok]
         b_of = torch.div(tok, S, rounding_mode="floor")
         sid = sample_ids.reshape(-1).to(torch.int64)[b_of] if sample_ids is not None else b_of
         rowmap = (sid * 512 + (tok - b_of * S)).to(torch.int32)
         cu = cu_seqlens.to(torch.int32)
-        mask = MaskInfo(None, B, S, input_ids.device, cu_seqlens=cu, rowmap=rowmap)
-        x = fused.embeddings_forward_packed(emb, ids, types, pos, rowmap)
+        mask = MaskInfo(None, B, S, tok.device, cu_seqlens=cu, rowmap=rowmap)
+        if emb is not None:
+            ids = input_ids.reshape(-1)[tok] if lookup else None
+            types = (token_type_ids.reshape(-1)[tok] if token_type_ids is not None else torch.zeros_like(tok))
+            pos = emb.position_ids(input_ids if lookup else None, B, S, tok.device).reshape(-1)[tok]
+            x = fused.embeddings_forward_packed(emb, ids, types, pos, rowmap, inputs_embeds)
+        else:
+            x = hidden_states
         for lyr in base.encoder.layers():
             x = fused.encoder_layer_forward(lyr, x, mask)
+        if not (run_head and getattr(self, "with_head", False)):
+            return SequenceClassifierOutput(last_hidden_state=x)
         first = x.index_select(0, cu[:-1].to(torch.int64)).unsqueeze(1)  # token 0 of every sample: [B, 1, H]
         res = self.head(first, labels)
         res.last_hidden_state = x
@@ -479,7 +496,8 @@ class BertForSequenceClassification(_ClassifierBase):
                 sample_ids=None, cu_seqlens=None, token_index=None, **unused):
         self._begin_forward(sample_ids)
         if self._can_run_unpadded(input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
-            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index)
+            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index, hidden_states,
+                                          attention_mask.shape if attention_mask is not None else None)
         out = self.bert(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack
@@ -541,7 +559,8 @@ class RobertaForSequenceClassification(_ClassifierBase):
                 sample_ids=None, cu_seqlens=None, token_index=None, **unused):
         self._begin_forward(sample_ids)
         if self._can_run_unpadded(input_ids, cu_seqlens, token_index, inputs_embeds, hidden_states, output_hidden_states):
-            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index)
+            return self._forward_unpadded(input_ids, token_type_ids, labels, sample_ids, cu_seqlens, token_index, hidden_states,
+                                          attention_mask.shape if attention_mask is not None else None)
         out = self.roberta(input_ids, attention_mask, token_type_ids, inputs_embeds, output_hidden_states, rng,
                         hidden_states)
         if not self.with_head:  # a pipeline stage that ends inside the encoder stack

@@ -78,12 +78,20 @@ class TriBert(nn.Module):
         token_type_ids = kwargs.pop("token_type_ids")
         labels = kwargs.pop("labels", None)
         sample_ids = kwargs.pop("sample_ids", None)
+        cu, tok = kwargs.pop("cu_seqlens", None), kwargs.pop("token_index", None)
         if self.verbose:
             print("Input shape ", input_ids.size())
         if self.runtime is not None:
             self.runtime.begin_forward(sample_ids, train=self.training and torch.is_grad_enabled())
         # the same embedding, pooler and classifier for the three towers
         word_embed = self.bert_1.get_input_embeddings()
+        if cu is not None and tok is not None and self.runtime is not None and input_ids.is_cuda:
+            # unpadded execution: one lookup of the real tokens, every tower on the packed [T, H] rows
+            firsts = _packed_towers((self.bert_1, self.bert_2, self.bert_3), word_embed(input_ids.reshape(-1)[tok]),
+                                    token_type_ids, sample_ids, cu, tok, input_ids.shape)
+            first = (firsts[0].float() + firsts[1].float() + firsts[2].float()) / 3.0
+            out = self.bert_1.head(first.to(firsts[0].dtype), labels)
+            return SequenceClassifierOutput(loss=out.loss, logits=out.logits, hidden_states=None, attentions=None)
         inputs_embeds = word_embed(input_ids)
         h1 = self._tower(self.bert_1, inputs_embeds, attention_mask, token_type_ids, self.first_device)
         h2 = self._tower(self.bert_2, inputs_embeds, attention_mask, token_type_ids, self.second_device)
@@ -93,6 +101,18 @@ class TriBert(nn.Module):
         first = (h1[:, :1].float() + h2[:, :1].to(dev).float() + h3[:, :1].to(dev).float()) / 3.0
         out = self.bert_1.head(first.to(h1.dtype), labels.to(dev) if labels is not None else None)
         return SequenceClassifierOutput(loss=out.loss, logits=out.logits, hidden_states=None, attentions=None)
+
+
+def _packed_towers(towers, inputs_embeds, token_type_ids, sample_ids, cu, tok, padded_shape):
+    """Every tower on the packed [T, H] word embeddings of an unpadded batch; returns the towers' token-0 rows
+    ([B, 1, H] each), the only rows the ensemble combines."""
+    rows = cu[:-1].to(torch.int64)
+    out = []
+    for t in towers:
+        h = t._forward_unpadded(None, token_type_ids, None, sample_ids, cu, tok, padded_shape=tuple(padded_shape),
+                                inputs_embeds=inputs_embeds, run_head=False).last_hidden_state
+        out.append(h.index_select(0, rows).unsqueeze(1))
+    return out
 
 
 class ConcatBert(nn.Module):
@@ -188,20 +208,33 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
     arena = inner.arena
     adt = arena.p16.dtype if (arena is not None and arena.p16 is not None) else torch.float32
     peer0, peer1 = mesh.peer(0), mesh.peer(1)
+    # unpadded execution (native kernels, collator with packing entries): the word embeddings and their gradient
+    # cross the link as packed [T, H] rows of the real tokens, the towers run on those rows
+    packed = rt is not None and dev.type == "cuda" and all(k in batch for k in ("cu_seqlens", "token_index", "lengths"))
+    cu, tok = (batch["cu_seqlens"], batch["token_index"]) if packed else (None, None)
+    emb_shape = (sum(int(v) for v in batch["lengths"]), H) if packed else (B, S, H)
+    sids = batch.get("sample_ids")
+
+    def run_towers(towers, emb_in):
+        if packed:
+            return _packed_towers(towers, emb_in, types, sids, cu, tok, (B, S))
+        return [t.base_model(inputs_embeds=emb_in, attention_mask=mask, token_type_ids=types).last_hidden_state[:, :1]
+                for t in towers]
+
     with torch.set_grad_enabled(train):
         if mesh.stage == 0:
             b1 = inner.bert_1
-            emb = b1.get_input_embeddings()(ids)
+            emb = b1.get_input_embeddings()(ids.reshape(-1)[tok] if packed else ids)
             _p2p([dist.P2POp(dist.isend, emb.detach().to(adt).contiguous(), peer1)])
             # tower 1 reads a detached copy, so the embedding lookup is differentiated ONCE, at the very end,
             # with the sum of this rank's and the peer's gradient
             emb_in = emb.detach().requires_grad_() if train else emb
-            h1 = b1.base_model(inputs_embeds=emb_in, attention_mask=mask, token_type_ids=types).last_hidden_state
+            h1 = run_towers([b1], emb_in)[0]
             s23 = torch.empty(B, 1, H, dtype=torch.float32, device=dev)
             _p2p([dist.P2POp(dist.irecv, s23, peer1)])
             if train:
                 s23.requires_grad_()
-            first = (h1[:, :1].float() + s23) / 3.0
+            first = (h1.float() + s23) / 3.0
             out = b1.head(first.to(h1.dtype), batch.get("labels"))
             if not train:
                 return out.loss, out.logits
@@ -214,7 +247,7 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
                 dp.prepare_backward()  # layer buckets are reduced while the rest of this backward still runs
             # tower-1 / head gradients; d(s23) goes to the second rank, which answers with d(embedding)
             loss.backward()
-            d_emb = torch.empty(B, S, H, dtype=adt, device=dev)
+            d_emb = torch.empty(*emb_shape, dtype=adt, device=dev)
             _p2p([dist.P2POp(dist.isend, s23.grad.contiguous(), peer1), dist.P2POp(dist.irecv, d_emb, peer1)])
             emb.backward(emb_in.grad.to(emb.dtype) + d_emb.to(emb.dtype))
             if rt is not None:
@@ -222,13 +255,12 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
             if dp is not None:
                 dp.finish_backward()  # the embedding bucket (and anything unused) is reduced here; then the join
             return out.loss.detach(), out.logits
-        emb = torch.empty(B, S, H, dtype=adt, device=dev)
+        emb = torch.empty(*emb_shape, dtype=adt, device=dev)
         _p2p([dist.P2POp(dist.irecv, emb, peer0)])
         if train:
             emb.requires_grad_()
-        hs = [t.base_model(inputs_embeds=emb, attention_mask=mask, token_type_ids=types).last_hidden_state
-              for t in inner.towers()]
-        s = hs[0][:, :1].float() + hs[1][:, :1].float()
+        hs = run_towers(inner.towers(), emb)
+        s = hs[0].float() + hs[1].float()
         _p2p([dist.P2POp(dist.isend, s.detach().contiguous(), peer0)])
         if not train:
             return None, None

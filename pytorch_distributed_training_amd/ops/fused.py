@@ -238,7 +238,10 @@ class _EmbedFn(torch.autograd.Function):
                                        SITE_EMBED + nat.site_offset, cfg.pad_token_id, acc, key.sample_ids, S, rowmap)
         ctx.saved = None
         nat.rt.done(nat.segment)
-        return None, None, None, None, None, (dsum.view(B, S, -1) if has_ie else None), None
+        d_ie = None
+        if has_ie:
+            d_ie = dsum.view(B * S, -1) if rowmap is not None else dsum.view(B, S, -1)
+        return None, None, None, None, None, d_ie, None
 
 
 def embeddings_forward(emb, input_ids, token_type_ids, pos_ids, inputs_embeds, rng=None):
@@ -251,9 +254,14 @@ def embeddings_forward(emb, input_ids, token_type_ids, pos_ids, inputs_embeds, r
                           inputs_embeds, None)
 
 
-def embeddings_forward_packed(emb, ids, type_ids, pos_ids, rowmap):
-    """Embeddings of the T real tokens of an unpadded batch (all arguments [T]); returns the packed [T, H] rows."""
-    return _EmbedFn.apply(emb.LayerNorm.weight, emb, ids, type_ids, pos_ids, None, rowmap)
+def embeddings_forward_packed(emb, ids, type_ids, pos_ids, rowmap, inputs_embeds=None):
+    """Embeddings of the T real tokens of an unpadded batch (index arguments [T]; `inputs_embeds`, when given instead
+    of `ids`, the packed [T, H] word embeddings); returns the packed [T, H] rows."""
+    nat: EmbedNative = emb._native
+    if inputs_embeds is not None and inputs_embeds.dtype != nat.w[0].dtype:
+        inputs_embeds = inputs_embeds.to(nat.w[0].dtype)
+    return _EmbedFn.apply(emb.LayerNorm.weight, emb, None if inputs_embeds is not None else ids, type_ids, pos_ids,
+                          inputs_embeds, rowmap)
 
 
 # --------------------------------------------------------------------------------------------------

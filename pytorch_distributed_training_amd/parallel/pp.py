@@ -61,11 +61,42 @@ def build_stage(model_cfg, stage: int, stages: int, full_state: Optional[Dict[st
     return part
 
 
-def _split_batch(batch: Dict[str, torch.Tensor], m: int) -> List[Dict[str, torch.Tensor]]:
-    n = next(iter(batch.values())).shape[0]
+_PACKED_KEYS = ("cu_seqlens", "token_index", "lengths")
+
+
+def _strip_packing(batch: Dict) -> Dict:
+    """The batch without the unpadded-execution entries of the collator (padded execution)."""
+    return {k: v for k, v in batch.items() if k not in _PACKED_KEYS}
+
+
+def _split_batch(batch: Dict, m: int) -> List[Dict]:
+    """Cut a batch into `m` micro-batches along the sample dimension.  A batch that carries the collator's packing
+    entries (``cu_seqlens`` [B+1], ``token_index`` [T], and the host-side list ``lengths``) is cut so that every
+    micro-batch is again a self-contained packed batch: its ``cu_seqlens`` start at 0, its ``token_index`` are
+    flat positions inside its own [b, S] block, and ``tokens`` is its row count as a host integer (the size of the
+    block that crosses the link) - all without reading anything back from the device."""
+    n = batch["attention_mask"].shape[0] if "attention_mask" in batch else next(iter(batch.values())).shape[0]
     m = max(1, min(m, n))
     bounds = [round(i * n / m) for i in range(m + 1)]
-    return [{k: v[bounds[i]:bounds[i + 1]] for k, v in batch.items()} for i in range(m)]
+    packed = all(k in batch for k in _PACKED_KEYS)
+    if not packed:
+        batch = _strip_packing(batch)
+        return [{k: v[bounds[i]:bounds[i + 1]] for k, v in batch.items()} for i in range(m)]
+    lengths = [int(v) for v in batch["lengths"]]
+    seq = batch["attention_mask"].shape[1]
+    starts = [0]
+    for v in lengths:
+        starts.append(starts[-1] + v)
+    out = []
+    for i in range(m):
+        b0, b1 = bounds[i], bounds[i + 1]
+        t0, t1 = starts[b0], starts[b1]
+        c = {k: v[b0:b1] for k, v in batch.items() if k not in _PACKED_KEYS}
+        c["cu_seqlens"] = batch["cu_seqlens"][b0:b1 + 1] - t0
+        c["token_index"] = batch["token_index"][t0:t1] - b0 * seq
+        c["tokens"] = t1 - t0
+        out.append(c)
+    return out
 
 
 def _p2p(ops, comm=None, pp: int = 2) -> None:
@@ -111,6 +142,10 @@ class PipelineStage:
         self.first, self.last = mesh.is_first_stage, mesh.is_last_stage
         self.prev, self.next = mesh.peer(0), mesh.peer(1)
         self.timers = {"p2p_wait_s": 0.0}
+        self.link_bytes = 0  # bytes this rank has put on / taken off the link (activations and their gradients)
+        # unpadded execution needs the native kernels on both stages; both ranks of a replica decide alike (same
+        # build, same device type, same precision mode)
+        self.packed = getattr(inner, "runtime", None) is not None and engine.device.type == "cuda"
         self.comm = None
         if (engine.device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl"
                 and backend_choice(getattr(engine, "comm_backend", None)) == "rccl"):
@@ -118,19 +153,27 @@ class PipelineStage:
 
     # -- communication -------------------------------------------------------------------------------
     def _buf(self, chunk: Dict[str, torch.Tensor]) -> torch.Tensor:
+        if "tokens" in chunk:  # packed micro-batch: only the rows of real tokens cross the link
+            return torch.empty(chunk["tokens"], self.hidden, dtype=self.act_dtype, device=self.engine.device)
         b, s = chunk["attention_mask"].shape
         return torch.empty(b, s, self.hidden, dtype=self.act_dtype, device=self.engine.device)
 
+    def _chunks(self, batch: Dict, m: int) -> List[Dict]:
+        return _split_batch(batch if self.packed else _strip_packing(batch), m)
+
     def _send(self, t: torch.Tensor, dst: int) -> None:
+        self.link_bytes += t.numel() * t.element_size()
         with trace_range("pp.send"):
             _p2p([dist.P2POp(dist.isend, t.contiguous(), dst)], self.comm, self.mesh.pp)
 
     def _recv(self, buf: torch.Tensor, src: int) -> torch.Tensor:
+        self.link_bytes += buf.numel() * buf.element_size()
         with trace_range("pp.recv"):
             _p2p([dist.P2POp(dist.irecv, buf, src)], self.comm, self.mesh.pp)
         return buf
 
     def _send_recv(self, t: torch.Tensor, buf: torch.Tensor, peer: int) -> torch.Tensor:
+        self.link_bytes += t.numel() * t.element_size() + buf.numel() * buf.element_size()
         with trace_range("pp.send_recv"):
             _p2p([dist.P2POp(dist.isend, t.contiguous(), peer), dist.P2POp(dist.irecv, buf, peer)], self.comm, self.mesh.pp)
         return buf
@@ -144,8 +187,8 @@ class PipelineStage:
         """Forward + backward of `batch` cut into micro-batches.  Returns the batch-mean loss on the last
         stage (None on the first).  Gradients accumulate in the arena; the data-parallel all-reduce is armed
         only for the final micro-batch's backward."""
-        chunks = _split_batch(batch, self.m)
-        m, total = len(chunks), next(iter(batch.values())).shape[0]
+        chunks = self._chunks(batch, self.m)
+        m, total = len(chunks), batch["attention_mask"].shape[0]
         self.module.train()
         if self.first:
             outs: List[Optional[torch.Tensor]] = []
@@ -168,7 +211,8 @@ class PipelineStage:
             act.requires_grad_()
             c = chunks[i]
             out = self.module(hidden_states=act, attention_mask=c["attention_mask"], labels=c["labels"],
-                              sample_ids=c.get("sample_ids"))
+                              sample_ids=c.get("sample_ids"), cu_seqlens=c.get("cu_seqlens"),
+                              token_index=c.get("token_index"))
             loss = out.loss * (c["labels"].shape[0] / total)  # exact batch-mean over unequal micro-batches
             if i == m - 1:
                 self._arm()
@@ -183,18 +227,21 @@ class PipelineStage:
 
     def _fwd_first(self, c: Dict[str, torch.Tensor]) -> torch.Tensor:
         out = self.module(input_ids=c["input_ids"], attention_mask=c["attention_mask"],
-                          token_type_ids=c.get("token_type_ids"), sample_ids=c.get("sample_ids"))
+                          token_type_ids=c.get("token_type_ids"), sample_ids=c.get("sample_ids"),
+                          cu_seqlens=c.get("cu_seqlens"), token_index=c.get("token_index"))
         return out.last_hidden_state
 
     @torch.no_grad()
     def eval_step(self, batch: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
         """Forward only; logits on the last stage."""
         self.module.eval()
+        batch = self._chunks(batch, 1)[0]
         if self.first:
             self._send(self._fwd_first(batch), self.next)
             return None
         act = self._recv(self._buf(batch), self.prev)
-        return self.module(hidden_states=act, attention_mask=batch["attention_mask"]).logits
+        return self.module(hidden_states=act, attention_mask=batch["attention_mask"], cu_seqlens=batch.get("cu_seqlens"),
+                           token_index=batch.get("token_index")).logits
 
     def optimizer_step(self, optimizer, scheduler=None) -> None:
         optimizer.step(overflow_group=self.mesh.pp_group if self.engine.scaler.enabled else None)
@@ -323,6 +370,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     dist.broadcast_object_list(box, src=ParallelMesh(world_size, 0, 2).peer(1))
     out = dict(box[0] or {})
     out.update({"optimizer_steps": global_step, "replicas_bit_equal": replicas_equal, "wall_s": time.perf_counter() - t0, "losses": losses,
-                "stage": mesh.stage, "replica": mesh.replica})
+                "stage": mesh.stage, "replica": mesh.replica, "packed": pipe.packed and bool(cfg.varlen),
+                "link_mb": pipe.link_bytes / 1e6})
     logger.close()
     return out

@@ -71,7 +71,7 @@ def make_model(cfg: TrainConfig):
 
 
 def _collator(cfg: TrainConfig, model_cfg) -> PadCollator:
-    varlen = bool(cfg.varlen) and cfg.pp_stages == 1  # (the model-parallel layouts exchange padded [B, S, H] blocks)
+    varlen = bool(cfg.varlen)  # (the model-parallel layouts hand packed rows across the link as well)
     if cfg.max_length:
         return PadCollator(model_cfg.pad_token_id, "max_length", cfg.max_length, varlen=varlen)
     mult = cfg.pad_to_multiple_of if (cfg.pad_to_multiple_of or 0) > 0 else None

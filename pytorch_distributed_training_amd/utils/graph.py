@@ -71,12 +71,15 @@ class GraphedStep:
 
     def _load(self, batches) -> None:
         if self.static is None:
-            self.static = [{k: v.to(self.engine.device).clone() for k, v in b.items()} for b in batches]
+            self.static = [{k: v.to(self.engine.device).clone() for k, v in b.items() if isinstance(v, torch.Tensor)}
+                           for b in batches]
             return
         if len(batches) != len(self.static):
             raise ValueError("number of micro-batches changed after capture")
         for dst, src in zip(self.static, batches):
             for k, v in src.items():
+                if not isinstance(v, torch.Tensor):
+                    continue
                 if dst[k].shape != v.shape:
                     raise ValueError(f"shape of batch[{k!r}] changed: {tuple(v.shape)} vs captured {tuple(dst[k].shape)}")
                 dst[k].copy_(v, non_blocking=True)

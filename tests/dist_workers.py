@@ -317,7 +317,7 @@ def gpu_dp_comm_fallback(rank, world):
     return out
 
 
-def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop"):
+def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
@@ -327,7 +327,7 @@ def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodro
         os.environ["PDT_DEBUG"] = "1"
     cfg = TrainConfig(model=model, fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
-                      seed=5, mp_layout=layout, init_scale=256.0)
+                      seed=5, mp_layout=layout, init_scale=256.0, varlen=varlen)
     if layout == "towers":
         cfg.batch_size, cfg.max_gpu_batch_size = 8, 8
     return run_model_parallel(rank, world, cfg)

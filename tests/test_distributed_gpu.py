@@ -46,6 +46,21 @@ def test_pipeline_native_loss_curve(world):
     assert all(r["replicas_bit_equal"] in (True, None) for r in res)
 
 
+def test_pipeline_hands_packed_rows_across_the_link():
+    """Dynamically padded batches: both stages run on the real tokens only and only those rows (and their gradients)
+    cross the link; the loss curve is the one of the padded run of the same recipe (dropout on: the masks are keyed
+    by sample and position, not by packed row)."""
+    runs = {}
+    for varlen in (True, False):
+        res = run_distributed(W.gpu_pipeline_recipe, 2, args=("pipeline", False, "bert-tiny", varlen))
+        runs[varlen] = [r for r in res if r["stage"] == 1][0]
+    packed, padded = runs[True], runs[False]
+    assert packed["packed"] is True and padded["packed"] is False
+    assert len(packed["losses"]) == len(padded["losses"]) == 6
+    assert max(abs(a - b) for a, b in zip(packed["losses"], padded["losses"])) < 1.5e-2, (packed["losses"], padded["losses"])
+    assert packed["link_mb"] < 0.9 * padded["link_mb"], (packed["link_mb"], padded["link_mb"])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_tower_parallel_native_loss_curve(world):
     """TriBert towers over rank pairs; with 4 ranks two such pairs are data parallel (fp16, debug guards on): the

@@ -508,3 +508,87 @@ def test_unpadded_execution_matches_the_padded_batch(name):
     m.eval()
     with torch.no_grad():
         torch.testing.assert_close(m(**batch).logits, m(**padded).logits, rtol=5e-3, atol=5e-3)
+
+
+def _ragged_batch(pad, lens=(37, 12, 64, 5, 29, 48), seed=2):
+    from pytorch_distributed_training_amd.data import PadCollator
+
+    g = torch.Generator().manual_seed(seed)
+    examples = [{"input_ids": torch.randint(5, 500, (n,), generator=g).tolist(), "attention_mask": [1] * n,
+                 "token_type_ids": [0] * (n // 2) + [1] * (n - n // 2), "labels": int(i % 2), "sample_ids": 40 + i}
+                for i, n in enumerate(lens)]
+    return PadCollator(pad, varlen=True)(examples).to("cuda")
+
+
+def test_unpadded_execution_of_a_two_stage_split():
+    """The packed [T, H] block a first stage produces, fed to a second stage together with the packing entries of
+    the batch, gives the loss and the parameter gradients of the whole model on that batch (dropout on)."""
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.models.config import preset
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+    from pytorch_distributed_training_amd.parallel.pp import build_stage
+
+    cfg = preset("bert-tiny")
+    torch.manual_seed(0)
+    full = build_model(cfg).cuda()
+    state = {k: v.detach().cpu().clone() for k, v in full.state_dict().items()}
+    arena = ParamArena(full, torch.device("cuda"), torch.float16)
+    full.enable_native(arena, seed=7, global_seed=5)
+    stages, arenas = [], []
+    for s in range(2):
+        part = build_stage(cfg, s, 2, state).cuda()
+        a = ParamArena(part, torch.device("cuda"), torch.float16)
+        part.enable_native(a, seed=7, global_seed=5)
+        stages.append(part.train())
+        arenas.append(a)
+    batch = _ragged_batch(cfg.pad_token_id)
+    T = int(batch["cu_seqlens"][-1])
+    full.train()
+    arena.zero_grad()
+    ref = full(**batch)
+    ref.loss.backward()
+    for a in arenas:
+        a.zero_grad()
+    packing = {k: batch[k] for k in ("cu_seqlens", "token_index", "sample_ids")}
+    h = stages[0](input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                  token_type_ids=batch["token_type_ids"], **packing).last_hidden_state
+    assert h.shape == (T, cfg.hidden_size)
+    act = h.detach().clone().requires_grad_()
+    out = stages[1](hidden_states=act, attention_mask=batch["attention_mask"], labels=batch["labels"], **packing)
+    out.loss.backward()
+    assert act.grad.shape == (T, cfg.hidden_size)
+    h.backward(act.grad)
+    torch.testing.assert_close(out.loss, ref.loss, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(out.logits, ref.logits, rtol=5e-3, atol=5e-3)
+    for a in arenas:
+        for name, (off, n) in a.offsets.items():
+            o = arena.offsets[name][0]
+            want, got = arena.grad[o:o + n], a.grad[off:off + n]
+            assert ((got - want).norm() / (want.norm() + 1e-6)).item() < 2e-2, name
+
+
+def test_unpadded_execution_of_the_tower_ensemble():
+    """TriBert on the real tokens only (one packed word-embedding lookup shared by the three towers) equals the
+    padded run: loss, logits, gradients - dropout on."""
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.models.tribert import TriBert
+    from pytorch_distributed_training_amd.ops.arena import ParamArena
+
+    torch.manual_seed(0)
+    m = TriBert(build_model("bert-tiny"), build_model("bert-tiny"), build_model("bert-tiny")).cuda()
+    arena = ParamArena(m, torch.device("cuda"), torch.float16)
+    m.enable_native(arena, seed=7, global_seed=5)
+    batch = _ragged_batch(m.config.pad_token_id)
+    padded = {k: v for k, v in batch.items() if k not in ("cu_seqlens", "token_index", "lengths")}
+    m.train()
+    arena.zero_grad()
+    out_p = m(**padded)
+    out_p.loss.backward()
+    g_p = arena.grad.clone()
+    arena.window -= 1
+    arena.zero_grad()
+    out_u = m(**batch)
+    out_u.loss.backward()
+    torch.testing.assert_close(out_u.logits, out_p.logits, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(out_u.loss, out_p.loss, rtol=2e-3, atol=2e-3)
+    assert g_p.abs().sum() > 0 and ((arena.grad - g_p).norm() / g_p.norm()).item() < 2e-2

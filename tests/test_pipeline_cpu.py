@@ -52,6 +52,34 @@ def test_split_batch_covers_everything():
     assert len(_split_batch(b, 100)) == 10
 
 
+def test_split_batch_keeps_packed_micro_batches_self_contained():
+    """A batch with the collator's packing entries is cut into micro-batches that are packed batches themselves."""
+    from pytorch_distributed_training_amd.data.collate import PadCollator
+
+    lens = [5, 3, 7, 2, 6, 4, 1]
+    ex = [{"input_ids": list(range(10, 10 + n)), "attention_mask": [1] * n, "token_type_ids": [0] * n, "label": i % 2}
+          for i, n in enumerate(lens)]
+    batch = PadCollator(0, "longest", pad_to_multiple_of=8, varlen=True)(ex)
+    assert batch["lengths"] == lens and batch["attention_mask"].shape == (7, 8)
+    parts = _split_batch(batch, 3)
+    assert [p["labels"].shape[0] for p in parts] == [2, 3, 2]
+    flat = batch["input_ids"].reshape(-1)
+    seen = 0
+    for p in parts:
+        b = p["labels"].shape[0]
+        own = lens[seen:seen + b]
+        assert p["tokens"] == sum(own) and p["cu_seqlens"].tolist() == [sum(own[:i]) for i in range(b + 1)]
+        # the micro-batch's token_index addresses its own [b, S] block and selects exactly its real tokens
+        sel = p["input_ids"].reshape(-1)[p["token_index"]]
+        assert sel.tolist() == [t for n in own for t in range(10, 10 + n)]
+        assert "lengths" not in p
+        seen += b
+    assert seen == len(lens) and flat.numel() == 56
+    # without the host-side lengths (or on a path that runs padded) the packing entries are dropped
+    padded = _split_batch({k: v for k, v in batch.items() if k != "lengths"}, 2)
+    assert all("cu_seqlens" not in p and "token_index" not in p for p in padded)
+
+
 def test_pipeline_loss_curve_matches_single_process():
     ref = W.single_process_reference(batch_size=16)
     res = run_distributed(W.pipeline_recipe, 2, args=(4, 4))  # 1 replica x 2 stages, 4 micro-batches of 4
