@@ -55,7 +55,7 @@ class TrainConfig:
     max_length: Optional[int] = None  # None: pad to the longest sample of each batch
     pad_to_multiple_of: Optional[int] = None
     # behaviour switches
-    varlen: bool = True         # native data-parallel path: run the encoder on the real tokens of a padded batch only
+    varlen: bool = True         # native path (all layouts): run the encoder on the real tokens of a padded batch only
     compat: bool = False        # reproduce the reference's quirks (see train_dp.py)
     max_steps: int = 0          # stop after this many optimizer steps (0 = run all epochs)
     log_every: int = 10
