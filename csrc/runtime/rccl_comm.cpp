@@ -268,6 +268,7 @@ void bind_rccl_comm(py::module_& m) {
       .def("all_reduce_async", &RcclComm::all_reduce_async, py::arg("tensor"), py::arg("average") = false)
       .def("broadcast_async", &RcclComm::broadcast_async, py::arg("tensor"), py::arg("root") = 0)
       .def("all_gather_async", &RcclComm::all_gather_async, py::arg("out"), py::arg("inp"))
+      .def("reduce_scatter_async", &RcclComm::reduce_scatter_async, py::arg("out"), py::arg("inp"), py::arg("average") = false)
       .def("p2p_async", &RcclComm::p2p_async, py::arg("kinds"), py::arg("tensors"), py::arg("peers"))
       .def("barrier", &RcclComm::barrier, py::call_guard<py::gil_scoped_release>())
       .def("synchronize", &RcclComm::synchronize, py::call_guard<py::gil_scoped_release>())

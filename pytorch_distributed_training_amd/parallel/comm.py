@@ -46,17 +46,44 @@ def _agree(ok: bool, group, device) -> bool:
 
 
 def self_test(comm) -> str:
-    """One small all-reduce on the communicator's own stream, waited for with a deadline (``PDT_COMM_SELFTEST_S``,
-    default 60 s) and checked for its value.  Returns "" if it passed, else what went wrong."""
+    """Exercise the communicator the way a training step does before anybody relies on it, every wait under a
+    deadline (``PDT_COMM_SELFTEST_S``, default 60 s), every result checked:
+
+    1. one small all-reduce on the communicator's own stream (the low-latency protocol);
+    2. three windows of ``fork -> two bucket-sized all-reduces (32 MB, averaged) -> join`` back to back with a
+       consumer kernel on the compute stream after every join and no host synchronisation in between - the pattern of
+       an overlapped backward; then a reduce-scatter + all-gather round over the same buffer.
+
+    Returns "" if everything passed, else what went wrong."""
     world = comm.world_size
-    probe = torch.ones(1024, dtype=torch.float32, device=torch.device("cuda", comm.device))
+    device = torch.device("cuda", comm.device)
+    deadline = float(os.environ.get("PDT_COMM_SELFTEST_S", "60"))
+    probe = torch.ones(1024, dtype=torch.float32, device=device)
     comm.fork()
     comm.all_reduce_async(probe, False)
-    if not comm.wait_idle(float(os.environ.get("PDT_COMM_SELFTEST_S", "60"))):
+    if not comm.wait_idle(deadline):
         return "the self-test all-reduce did not finish"
     comm.join()
     if not bool((probe == float(world)).all().item()):
         return f"the self-test all-reduce returned {probe[0].item()} instead of {world}"
+    n = (8 << 20) // world * world
+    bucket = torch.full((n,), float(comm.rank + 1), dtype=torch.float32, device=device)
+    mean = (world + 1) / 2.0  # average of rank+1 over the ranks; averaging it again leaves it unchanged
+    for _ in range(3):
+        comm.fork()
+        comm.all_reduce_async(bucket, True)
+        comm.all_reduce_async(bucket, True)
+        comm.join()
+        bucket.mul_(1.0)  # a consumer on the compute stream, ordered behind the join
+    shard = torch.empty(n // world, dtype=torch.float32, device=device)
+    comm.fork()
+    comm.reduce_scatter_async(shard, bucket, True)
+    comm.all_gather_async(bucket, shard)
+    if not comm.wait_idle(deadline):
+        return "the chained bucket collectives of the self test did not finish"
+    comm.join()
+    if not bool(torch.allclose(bucket, torch.full_like(bucket, mean), rtol=1e-6, atol=1e-6)):
+        return f"the chained bucket collectives returned {bucket[0].item()} instead of {mean}"
     return ""
 
 
@@ -64,8 +91,9 @@ def create_rccl_comm(group=None, device: Optional[torch.device] = None):
     """Open (once per group) an RcclComm spanning the ranks of `group` (default: all ranks; a process that has
     no process group gets a 1-rank communicator).  Collective over the group: every member must call it.
 
-    A communicator of more than one rank is self-tested before anybody relies on it: one small all-reduce on its own
-    stream, waited for with a deadline (``PDT_COMM_SELFTEST_S``, default 60 s) and checked for its value.  The ranks
+    A communicator of more than one rank is self-tested before anybody relies on it (`self_test`: a small all-reduce,
+    then bucket-sized collectives chained the way an overlapped backward issues them, every wait under the deadline
+    ``PDT_COMM_SELFTEST_S``, default 60 s, every result checked).  The ranks
     agree on the outcome over the process group; if any rank failed to construct the communicator, timed out or read
     a wrong sum, every rank aborts its communicator and ``None`` is returned - the callers then route the traffic
     through the process group itself (torch's "nccl" backend) instead of hanging the job."""
