@@ -4,6 +4,8 @@
 #   bash bench/scale_sweep.sh [steps] [warmup] [extra bench.py flags...]
 # With PDT_SWEEP_MP=1 the data-parallel x 2-stage-pipeline layout follows on all visible GPUs: bench.py --pp 2
 # (BERT-large seq 128 fp16, RoBERTa-large seq 512 bf16) and python train_mp.py --fp16=True --max-steps 20.
+# With PDT_SWEEP_COMM=1 a gradient-transport matrix follows on all visible GPUs (communicator, bucket algorithm,
+# wire dtype, persistent GEMMs, RCCL channel count).
 set -euo pipefail
 cd "$(dirname "$0")/.."
 STEPS=${1:-20}; WARMUP=${2:-5}; shift $(( $# > 2 ? 2 : $# )) || true
@@ -32,4 +34,21 @@ if [ "${PDT_SWEEP_MP:-0}" = "1" ] && [ "$NGPU" -ge 2 ]; then
       bench.py --gpus "$n" --pp 2 --micro-batches 8 --steps "$STEPS" --warmup "$WARMUP" $extra | tail -1
   done
   python train_mp.py --fp16=True --max-steps 20 --log-every 1
+fi
+if [ "${PDT_SWEEP_COMM:-0}" = "1" ] && [ "$NGPU" -ge 2 ]; then
+  # gradient-transport matrix on all GPUs: who drives RCCL, how a bucket is reduced, wire dtype, persistent GEMMs
+  # next to the communication kernels, RCCL channel count.  Compare "value" and "comm_exposed_ms_per_step".
+  run() { # run <label> <env assignments...> -- <bench flags...>
+    local label=$1; shift; local envs=()
+    while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+    echo "# $label"
+    env "${envs[@]}" python -m torch.distributed.run --nnodes=1 --nproc-per-node "$NGPU" --master-addr 127.0.0.1 \
+      --master-port 29670 bench.py --gpus "$NGPU" --steps "$STEPS" --warmup "$WARMUP" "$@" | tail -1
+  }
+  run "own communicator, all-reduce buckets (default)" PDT_X=0 --
+  run "torch process group" PDT_X=0 -- --comm c10d
+  run "reduce-scatter + all-gather buckets" PDT_X=0 -- --comm-algo rs_ag
+  run "bf16 on the wire" PDT_X=0 -- --comm-dtype bf16
+  run "persistent GEMM launches next to the collectives" PDT_GEMM_PERSIST=1 --
+  for ch in 8 16 32; do run "RCCL channels pinned to $ch" NCCL_MIN_NCHANNELS=$ch NCCL_MAX_NCHANNELS=$ch --; done
 fi
