@@ -1,6 +1,8 @@
-"""Data-parallel plumbing on 2 CPU processes over gloo (the C++ bucket reducer runs unchanged on CPU tensors)."""
+"""Data-parallel plumbing on 2 (and 8) CPU processes over gloo (the C++ bucket reducer runs unchanged on CPU tensors)."""
 import os
 import sys
+
+import pytest
 
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -14,8 +16,9 @@ def test_native_reducer_is_loaded():
     assert available(), "the C++ extension (bucket reducer) must be built: python build_ext.py"
 
 
-def test_dp_gradients_equal_single_process_big_batch():
-    res = run_distributed(W.dp_grads_match_big_batch, 2)
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_gradients_equal_single_process_big_batch(world):
+    res = run_distributed(W.dp_grads_match_big_batch, world)
     for r in res:
         assert r["worst"] < 1e-6
         assert r["nb"] >= 3
