@@ -78,8 +78,7 @@ extern "C" void pdt_gemm_set_persist_mode(int mode) { g_persist_mode = mode < 0 
 // number of fp32 slabs a weight-gradient GEMM of this shape will write (what the caller must allocate)
 // K split of forward / dgrad GEMMs with few output tiles (pdt_gemm_splits): on by default - a lone short micro-batch
 // is latency-bound and a split K shortens every GEMM of the dependent chain (BERT-large, batch 8: 809 vs 745
-// samples/s).  Off while two micro-batches are in flight on two streams (Engine.accumulate): the second stream
-// fills the idle CUs, and the saved epilogue launches count for more (12 x 8: 1262 vs 1217 samples/s).
+// samples/s; with two micro-batches in flight on two streams, Engine.accumulate, 12 x 8: 1453 vs 1397).
 static int g_split_fwd = 1;
 extern "C" void pdt_gemm_set_split_mode(int on) { g_split_fwd = on ? 1 : 0; }
 extern "C" int pdt_gemm_split_mode(void) { return g_split_fwd; }
@@ -103,8 +102,9 @@ extern "C" int pdt_gemm_splits(int layout, int tile, const PdtGemm* g) {
   const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128);
   const int ktiles = (g->K + 63) / 64;
   if (!g_split_fwd) return 1;
+  static const int min_kt = [] { const char* e = getenv("PDT_SPLIT_MIN_KT"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
   int s = (int)((2 * kNumCU) / t128);
-  if (s > ktiles / 16) s = ktiles / 16;
+  if (s > ktiles / min_kt) s = ktiles / min_kt;
   if (s > 8) s = 8;
   return s < 2 ? 1 : s;
 }

@@ -9,6 +9,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <functional>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../kernels/api.h"
@@ -38,20 +41,54 @@ int g_wgrad_mode = [] {
   return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
 }();
 constexpr int kWgradLaneMaxTokens = 12288;
+// Deferred mode (set_wgrad_defer(true), used by Engine.accumulate for every backward of an accumulation window but
+// the last): short micro-batches are bound by how fast the host can enqueue, and the four forks and the join of a
+// layer are 10 of its ~25 runtime calls.  A deferred lane queues the layer's weight-gradient GEMMs, issues them
+// behind ONE fork at the end of the layer and does not join: nothing on the main stream reads those gradients
+// before the backward pass is over.  The tensors the queued GEMMs read are kept alive (per main stream) until
+// wgrad_join() has made the main stream wait for the side stream, which the caller does once, after backward().
+bool g_wgrad_defer = false;
+std::mutex g_defer_mu;
+std::unordered_map<int64_t, std::vector<Tensor>> g_defer_held;  // by main-stream id
 class WgradLane {
  public:
-  explicit WgradLane(bool enabled) : on_(enabled), main_(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA()), side_(main_) {
+  explicit WgradLane(bool enabled, bool defer = false)
+      : on_(enabled), defer_(enabled && defer), main_(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA()), side_(main_) {
     if (on_) side_ = side_stream(main_.device_index());
   }
   // run `fn` (kernel launches + its temporaries) on the side stream, after everything issued so far on main
+  // (deferred: after everything issued on main up to finish()); `reads` are the tensors it reads
   template <typename F>
-  void run(F&& fn) {
+  void run(F&& fn, std::initializer_list<Tensor> reads = {}) {
     if (!on_) { fn(); return; }
+    if (defer_) {
+      pending_.emplace_back(std::forward<F>(fn));
+      keep_.insert(keep_.end(), reads.begin(), reads.end());
+      return;
+    }
     event(next_++).record(main_);
     event(next_ - 1).block(side_);
     StreamGuard g(side_);
     fn();
     used_ = true;
+  }
+  // end of the layer: join (or, deferred, fork once and issue what was queued)
+  void finish() {
+    if (defer_ && !pending_.empty()) {
+      event(next_++).record(main_);
+      event(next_ - 1).block(side_);
+      {
+        StreamGuard g(side_);
+        for (auto& fn : pending_) fn();
+      }
+      pending_.clear();
+      std::lock_guard<std::mutex> lock(g_defer_mu);
+      auto& held = g_defer_held[(int64_t)main_.id()];
+      held.insert(held.end(), keep_.begin(), keep_.end());
+      keep_.clear();
+      return;
+    }
+    join();
   }
   void join() {
     if (!on_ || !used_) return;
@@ -59,7 +96,26 @@ class WgradLane {
     event(next_ - 1).block(main_);
     used_ = false;
   }
-  ~WgradLane() { join(); }
+  // (queued launches are only ever issued by finish(): they capture the caller's locals, which are gone by the time
+  // a destructor runs during stack unwinding)
+  ~WgradLane() { pending_.clear(); join(); }
+  // make the current stream wait for the side stream and drop the tensors kept for it (see g_wgrad_defer)
+  static void join_deferred() {
+    Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+    std::vector<Tensor> drop;
+    {
+      std::lock_guard<std::mutex> lock(g_defer_mu);
+      auto it = g_defer_held.find((int64_t)main.id());
+      if (it == g_defer_held.end() || it->second.empty()) return;
+      drop.swap(it->second);
+    }
+    Stream side = side_stream(main.device_index());
+    at::cuda::CUDAEvent& e = event(15);
+    e.record(side);
+    e.block(main);
+    // (`drop` is released here: the caching allocator hands the blocks back to the stream they belong to, whose
+    // later work is ordered behind the wait above)
+  }
 
  private:
   static Stream side_stream(c10::DeviceIndex dev) {
@@ -68,15 +124,17 @@ class WgradLane {
     return *streams[dev];
   }
   // events are re-recorded every layer: a small per-thread ring, never destroyed while work may reference them
-  at::cuda::CUDAEvent& event(int i) {
+  static at::cuda::CUDAEvent& event(int i) {
     static thread_local std::vector<std::unique_ptr<at::cuda::CUDAEvent>> ring(16);
     auto& e = ring[i & 15];
     if (!e) e = std::make_unique<at::cuda::CUDAEvent>();
     return *e;
   }
-  bool on_, used_ = false;
+  bool on_, defer_, used_ = false;
   int next_ = 0;
   Stream main_, side_;
+  std::vector<std::function<void()>> pending_;
+  std::vector<Tensor> keep_;
 };
 
 int dt_code(const Tensor& t) {
@@ -384,18 +442,18 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
   // FFN2 dgrad fused with GELU' and with the FFN1 bias gradient (column sums of dU) ; wgrad
   Epi e_dg; e_dg.kind = PDT_EPI_MUL_DGELU; e_dg.aux = const_cast<Tensor*>(&u);
   e_dg.colsum = &gr[7]; e_dg.colsum_accumulate = accumulate; e_dg.fq = &fq;
-  WgradLane lane(g_wgrad_mode == 2 || (g_wgrad_mode == 1 && T <= kWgradLaneMaxTokens));
-  lane.run([&] { gemm_tn_into(l2.ddrop, gact, gr[8], accumulate); });
+  WgradLane lane(g_wgrad_mode == 2 || (g_wgrad_mode == 1 && T <= kWgradLaneMaxTokens), g_wgrad_defer);
+  lane.run([&] { gemm_tn_into(l2.ddrop, gact, gr[8], accumulate); }, {l2.ddrop, gact});
   Tensor du = gemm_nn(l2.ddrop, w[8], e_dg);
   // FFN1 dgrad + residual gradient ; wgrad
   Epi e_add; e_add.kind = PDT_EPI_ADD_RES; e_add.res = &l2.dx;
-  lane.run([&] { gemm_tn_into(du, x1, gr[6], accumulate); });
+  lane.run([&] { gemm_tn_into(du, x1, gr[6], accumulate); }, {du, x1});
   Tensor dx1 = gemm_nn(du, w[6], e_add);
   // LN1
   LnBwdOut l1 = ln_bwd(dx1, z1, stats1, w[4], &gr[4], &gr[5], &gr[3], p_hidden, make_rng(rng_state, micro, site + 1, sids, S, B, rowmap),
                        accumulate, &fq);
   // attention output projection
-  lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); });
+  lane.run([&] { gemm_tn_into(l1.ddrop, ctx, gr[2], accumulate); }, {l1.ddrop, ctx});
   Tensor dctx = gemm_nn(l1.ddrop, w[2], Epi{});
   // attention core
   Tensor dqkv = at::empty_like(qkv);
@@ -415,10 +473,12 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
     colsum_into(dqkv, gr[1], accumulate);
   // QKV projection dgrad + residual gradient ; wgrad
   Epi e_add2; e_add2.kind = PDT_EPI_ADD_RES; e_add2.res = &l1.dx;
-  lane.run([&] { gemm_tn_into(dqkv, x, gr[0], accumulate); });
+  lane.run([&] { gemm_tn_into(dqkv, x, gr[0], accumulate); }, {dqkv, x});
   Tensor dx = gemm_nn(dqkv, w[0], e_add2);
   fq.flush();
-  lane.join();  // the layer's gradients are complete on the main stream from here (bucket all-reduce, next layer)
+  // the layer's gradients are complete on the main stream from here (bucket all-reduce, next layer) - or, deferred,
+  // once the caller has joined after the backward pass
+  lane.finish();
   (void)T; (void)H;
   return dx;
 }
@@ -739,6 +799,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("op_attn_bwd", &op_attn_bwd, py::arg("qkv"), py::arg("mask"), py::arg("kv_len"), py::arg("ctx"), py::arg("dctx"),
         py::arg("lse"), py::arg("B"), py::arg("S"), py::arg("A"), py::arg("rng_state"), py::arg("p"), py::arg("micro"),
         py::arg("site"), py::arg("dbias") = py::none(), py::arg("sample_ids") = py::none(), py::arg("cu_seqlens") = py::none());
+  m.def("set_wgrad_defer", [](bool on) { g_wgrad_defer = on; },
+        "queue a layer's weight-gradient GEMMs behind one fork and skip the per-layer join (call wgrad_join after backward)");
+  m.def("wgrad_join", [] { WgradLane::join_deferred(); },
+        "current stream waits for the deferred weight-gradient GEMMs issued from it; releases the tensors kept for them");
   m.def("set_wgrad_side_stream", [](int64_t mode) { g_wgrad_mode = (int)mode; },
         "weight-gradient GEMMs of layer_backward on a second HIP stream: 0 never, 1 up to 12288 tokens (default), 2 always");
   m.def("set_gemm_persistent", [](int64_t mode) { pdt_gemm_set_persist_mode((int)mode); },

@@ -275,8 +275,13 @@ class Engine:
             threaded = os.environ.get("PDT_OVERLAP_THREAD", "1") != "0"
             from .ops import native as _native
 
+            defer_ok = os.environ.get("PDT_WGRAD_DEFER", "1") != "0"
             split_k = _native().gemm_split_k()
-            _native().set_gemm_split_k(False)  # two chains share the CUs: fewer launches beat shorter GEMMs here
+            # (K-split forward / dgrad GEMMs stay on inside the window: 1453 vs 1397 samples/s at 12 x 8 samples;
+            # PDT_OVERLAP_SPLITK=0 switches them off for the window, which was the faster setting while a layer's
+            # backward still cost 25 runtime calls on the host)
+            if os.environ.get("PDT_OVERLAP_SPLITK", "1") == "0":
+                _native().set_gemm_split_k(False)
             cur, done = forward(0), [None, None]
             for i in range(n):
                 nxt = None
@@ -295,11 +300,20 @@ class Engine:
                             dp.prepare_backward()
                     if dual and i == n - 1:
                         rt.merge_on_done = True
+                    # every backward of the window but the last: nothing reads the weight gradients before the
+                    # window ends, so the layers queue their weight-gradient GEMMs behind one fork each and the
+                    # stream joins once, here, instead of once per layer (fewer runtime calls per layer)
+                    defer = dual and i < n - 1 and defer_ok
+                    if defer:
+                        _native().set_wgrad_defer(True)
                     try:
                         cur[1].backward()
                     finally:
                         if dual:
                             rt.merge_on_done = False
+                        if defer:
+                            _native().set_wgrad_defer(False)
+                            _native().wgrad_join()
                     if dual and i == n - 1:
                         rt.arena.merge_alt()  # (segments that no node of the last backward reported)
                     done[i % 2] = torch.cuda.Event()
