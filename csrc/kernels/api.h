@@ -73,7 +73,8 @@ typedef struct PdtGemm {
 
 // tile: 0 = 128x128 (4 waves, double-buffered, 2 workgroups per CU), 1 = 256x256 (8 waves, one barrier per K-tile),
 // 2 = 256x256 ping-pong (8 waves in two staggered groups, counted LDS-DMA waits), 3 = 128x128 with a 4-deep K-tile
-// ring (1 workgroup per CU; for launches of about one workgroup per CU or fewer), -1 = choose from the shape.
+// ring (1 workgroup per CU; for launches of about one workgroup per CU or fewer), 4 = 64x128 and 5 = 64x64 on the same
+// ring (NT / NN resp. NT only: outputs with fewer 128x128 tiles than CUs), -1 = choose from the shape.
 // For TN, C is the fp32 slab buffer [splits][M][ldc] and g->splits / k_per_split select the K split
 // (0 = choose); the chosen values are written back into *g.
 int pdt_gemm(int dtype, int layout, int tile, PdtGemm* g, void* stream);

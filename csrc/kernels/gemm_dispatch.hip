@@ -22,6 +22,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // tile variant for a shape (tile >= 0: the caller's choice)
 static int choose_tile(int layout, int tile, const PdtGemm* g) {
+  if (tile == 4 || tile == 5) {  // 64-row tiles exist for K-contiguous A (4) and for forward GEMMs only (5)
+    if (layout == PDT_GEMM_TN) return 3;
+    if (layout == PDT_GEMM_NN) return 4;
+  }
   if (tile >= 0) return tile;
   // measured on MI355X (bench/gemm_bench.py, BERT-large shapes, 1024..32768 tokens): the ping-pong 256x256
   // kernel wins for forward / dgrad once its tiles fill at least 3/4 of the 256 CUs (at exactly 128 tiles the
@@ -34,7 +38,12 @@ static int choose_tile(int layout, int tile, const PdtGemm* g) {
   // back-to-back micro-benchmark, where they sit in L2, it is not.  PDT_GEMM_DEEP=<tiles> moves the bound (0: never).
   static const int deep = [] { const char* e = getenv("PDT_GEMM_DEEP"); return e ? atoi(e) : 320; }();
   const int64_t t128 = (int64_t)((g->M + 127) / 128) * ((g->N + 127) / 128);
-  const int small = (deep > 0 && t128 <= deep) ? 3 : 0;
+  int small = (deep > 0 && t128 <= deep) ? 3 : 0;
+  // a quarter of the CUs or fewer in 128x128 tiles (1024 tokens x 1024 outputs): 64x128 tiles on the same ring -
+  // 9.4 against 14.8 us for 1024^3 in a back-to-back run (hipBLASLt's 64x64 kernel: 8.6); wider outputs (192-256
+  // tiles of 128x128) are 15-20 % slower in 64-row tiles.  PDT_GEMM_SMALL64=<tiles> moves the bound (0: never).
+  static const int small64 = [] { const char* e = getenv("PDT_GEMM_SMALL64"); return e ? atoi(e) : 64; }();
+  if (small == 3 && layout != PDT_GEMM_TN && t128 <= small64) small = 4;
   if (layout == PDT_GEMM_TN)
     return (g->M >= 256 && g->N >= 256 && g->K >= 8192 && (t256 >= 32 || g->K >= 32768)) ? 2 : small;
   return t256 >= 192 ? 2 : small;

@@ -161,6 +161,14 @@ static int launch_dtype(int tile, PdtGemm& g, hipStream_t stream) {
   if (tile == 2) return launch_pingpong<T>(g, stream);
   if (tile == 1) return launch_tile<T, 256, 256, 2, 4>(g, stream);
   if (tile == 3) return launch_tile<T, 128, 128, 2, 2, 4>(g, stream);
+  // short micro-batches (few 128x128 tiles for 256 CUs): 64-row tiles on the ring kernel, 32 x 64 per wave.  A
+  // K-strided operand image needs a 256-B pitch for its swizzle (128 columns), so the weight gradients and the
+  // 64-column variant of the data gradients do not exist.
+  if (tile == 4 && !PDT_AKS) return launch_tile<T, 64, 128, 2, 2, 4>(g, stream);
+#if !PDT_AKS && !PDT_BKS
+  if (tile == 5) return launch_tile<T, 64, 64, 2, 1, 4>(g, stream);
+#endif
+  if (tile == 4 || tile == 5) return launch_tile<T, 128, 128, 2, 2, 4>(g, stream);
   return launch_tile<T, 128, 128, 2, 2>(g, stream);
 }
 

@@ -256,7 +256,7 @@ void run_gemm(int layout, const Tensor& A, const Tensor& B, Tensor& C, int M, in
   if (e.colsum) {
     chkf32(*e.colsum, "colsum");
     TORCH_CHECK(e.colsum->numel() == N, "colsum must have N elements");
-    cs_part = at::empty({2 * (((int64_t)M + 127) / 128), (int64_t)N}, C.options().dtype(at::kFloat));
+    cs_part = at::empty({2 * (((int64_t)M + 63) / 64), (int64_t)N}, C.options().dtype(at::kFloat));
     g.colsum = cs_part.data_ptr<float>();
   }
   // few output tiles + long K: split K over fp32 partial slabs, summed by the epilogue kernel

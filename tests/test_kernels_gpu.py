@@ -38,7 +38,7 @@ def rng_state(seed=1234, offset=0):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 384, 192), (1024, 768, 1024), (77, 128, 128)])
 def test_gemm_nt_plain_and_bias(dtype, tile, M, N, K):
     torch.manual_seed(0)
@@ -64,7 +64,7 @@ def test_gemm_nt_asymmetric_identity(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_gemm_nt_gelu_and_residual_epilogues(dtype, tile):
     torch.manual_seed(1)
     M, N, K = 520, 512, 256
@@ -107,7 +107,7 @@ def test_gemm_dropout_epilogue_statistics_and_replay(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (333, 512, 768), (1024, 1024, 3072)])
 def test_gemm_nn_dgrad(dtype, tile, M, N, K):
     torch.manual_seed(2)
@@ -146,7 +146,7 @@ def test_gemm_nn_asymmetric_identity(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("T,M,N", [(64, 256, 256), (1000, 512, 256), (4096, 768, 3072), (130, 128, 384)])
 def test_gemm_tn_wgrad(dtype, tile, T, M, N):
     torch.manual_seed(3)
