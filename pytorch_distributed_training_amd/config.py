@@ -34,7 +34,7 @@ class TrainConfig:
     seed: int = 42
     batch_size: int = 96
     # reference module constants
-    max_gpu_batch_size: int = 8
+    max_gpu_batch_size: int = 0  # 0: sized for the device (the reference's 8 on CPU / with --compat), see micro_batch_cap
     eval_batch_size: int = 32
     # reference literals
     model: str = "bert-large-cased"
@@ -73,10 +73,30 @@ class TrainConfig:
     save_every: int = 0
     init_from: Optional[str] = None  # directory with HF-layout weights (config.json + safetensors / bin)
 
-    def accumulation(self):
-        """The reference's accumulation policy (/root/reference/test_data_parallelism.py:90-93)."""
-        if self.batch_size > self.max_gpu_batch_size:
-            return self.batch_size // self.max_gpu_batch_size, self.max_gpu_batch_size
+    def micro_batch_cap(self, device=None, model_cfg=None) -> int:
+        """Largest micro-batch one GPU runs.  An explicit ``--max-gpu-batch-size N`` wins.  0 (default) sizes it for the
+        GPU the process drives: the reference's constant 8 (/root/reference/test_data_parallelism.py:49, chosen for
+        16-GB cards) on the CPU and with ``--compat``; on a GPU as many samples as fit a budget of half the free HBM
+        and at most 131072 tokens (the shape the kernels are tuned for), counting a sample at the longest length the
+        collator can produce and ~34 bytes of saved activations per token, layer and hidden unit (measured: 106 GB
+        for 131072 tokens of BERT-large)."""
+        if self.max_gpu_batch_size > 0:
+            return self.max_gpu_batch_size
+        if self.compat or device is None or getattr(device, "type", "cpu") != "cuda" or model_cfg is None:
+            return 8
+        import torch
+
+        free, _total = torch.cuda.mem_get_info(device)
+        per_token = 34 * model_cfg.num_hidden_layers * model_cfg.hidden_size
+        seq = self.max_length or model_cfg.max_position_embeddings
+        tokens = min(131072, int(0.5 * free) // per_token)
+        return max(8, tokens // max(1, seq))
+
+    def accumulation(self, device=None, model_cfg=None):
+        """The reference's accumulation policy (/root/reference/test_data_parallelism.py:90-93) on `micro_batch_cap`."""
+        cap = self.micro_batch_cap(device, model_cfg)
+        if self.batch_size > cap:
+            return self.batch_size // cap, cap
         return 1, self.batch_size
 
 

@@ -297,7 +297,7 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
                     comm_backend=cfg.comm_backend)
     model_cfg = preset(cfg.model)
     train_ds, val_ds = build_datasets(cfg, model_cfg)
-    accum, micro_bs = cfg.accumulation()
+    accum, micro_bs = cfg.accumulation(engine.device, model_cfg)
     collate = _collator(cfg, model_cfg)
     train_dl, eval_dl = model_parallel_loaders(cfg, train_ds, val_ds, collate, mesh, micro_bs)
     set_seed(cfg.seed)

@@ -281,7 +281,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
                     comm_backend=cfg.comm_backend)
     model_cfg = preset(cfg.model) if not cfg.init_from else ckpt.EncoderConfig.load(cfg.init_from)
     train_ds, val_ds = build_datasets(cfg, model_cfg)
-    accum, micro_bs = cfg.accumulation()
+    accum, micro_bs = cfg.accumulation(engine.device, model_cfg)
     collate = _collator(cfg, model_cfg)
     # one loader batch = one optimizer step = `accum` pipeline micro-batches
     train_dl, eval_dl = model_parallel_loaders(cfg, train_ds, val_ds, collate, mesh, micro_bs * accum)

@@ -129,7 +129,8 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     model_cfg = preset(cfg.model) if not cfg.init_from else ckpt.EncoderConfig.load(cfg.init_from)
     train_ds, val_ds = build_datasets(cfg, model_cfg)
     metric = load_metric("glue", "mrpc")
-    accum, micro_bs = cfg.accumulation()
+    accum, micro_bs = cfg.accumulation(engine.device, model_cfg)
+    engine.print(f"batch {cfg.batch_size} per process = {accum} micro-batch(es) of {micro_bs}")
     collate = _collator(cfg, model_cfg)
     train_dl = DataLoader(train_ds, shuffle=True, collate_fn=collate, batch_size=micro_bs)
     eval_dl = DataLoader(val_ds, shuffle=False, collate_fn=collate, batch_size=cfg.eval_batch_size)

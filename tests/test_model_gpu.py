@@ -592,3 +592,18 @@ def test_unpadded_execution_of_the_tower_ensemble():
     torch.testing.assert_close(out_u.logits, out_p.logits, rtol=5e-3, atol=5e-3)
     torch.testing.assert_close(out_u.loss, out_p.loss, rtol=2e-3, atol=2e-3)
     assert g_p.abs().sum() > 0 and ((arena.grad - g_p).norm() / g_p.norm()).item() < 2e-2
+
+
+def test_micro_batch_cap_is_sized_for_the_hbm_of_this_gpu():
+    """Unset, the micro-batch cap of the recipes is sized for the device: the reference's whole batch of 96 runs as
+    one micro-batch (its constant 8 was chosen for 16-GB cards), capped at 131072 tokens at the longest length."""
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.models.config import preset
+
+    dev = torch.device("cuda", 0)
+    large = preset("bert-large-cased")
+    cap = TrainConfig().micro_batch_cap(dev, large)
+    assert 96 <= cap <= 131072 // large.max_position_embeddings
+    assert TrainConfig().accumulation(dev, large) == (1, 96)
+    assert TrainConfig(max_length=128).micro_batch_cap(dev, large) <= 1024
+    assert TrainConfig(max_gpu_batch_size=8).accumulation(dev, large) == (12, 8)
