@@ -317,7 +317,7 @@ def gpu_dp_comm_fallback(rank, world):
     return out
 
 
-def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True):
+def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True, examples=64):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
@@ -325,7 +325,7 @@ def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodro
         import os
 
         os.environ["PDT_DEBUG"] = "1"
-    cfg = TrainConfig(model=model, fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
+    cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2,
                       batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
                       seed=5, mp_layout=layout, init_scale=256.0, varlen=varlen)
     if layout == "towers":
@@ -367,7 +367,7 @@ def gpu_dp_dropout(rank, world, steps=6):
     return losses
 
 
-def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop"):
+def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", examples=64):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
     from pytorch_distributed_training_amd.models.tribert import TriBert
@@ -376,7 +376,7 @@ def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop"):
     from pytorch_distributed_training_amd.utils.seed import set_seed
 
     bs = (8 if layout in ("towers", "dp") else 16) * replicas  # the global batch of `replicas` data-parallel replicas
-    cfg = TrainConfig(model=model, fp16=True, train_examples=64, eval_examples=16, num_epochs=2,
+    cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2,
                       batch_size=bs, seed=5)
     eng = Engine(fp16=True, seed=5, init_scale=256.0)
     mc = preset(cfg.model)

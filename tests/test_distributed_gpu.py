@@ -97,6 +97,19 @@ def test_dropout_masks_follow_the_sample_across_parallel_layouts():
     assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
 
 
+def test_eight_ranks_as_four_pipeline_pairs_reproduce_the_single_process_loss_curve():
+    """The layout of a whole node - 4 data-parallel replicas x 2 pipeline stages, rank = replica * 2 + stage
+    (/root/reference/test_model_parallelism.py:244-253 on 8 devices) - rehearsed with 8 processes on the one GPU, fp16,
+    dropout 0.1 on: six optimizer steps on a global batch of 64 give the loss curve of ONE process on that batch, and
+    the four replicas of each stage end bit-identical."""
+    ref = W.gpu_single_reference("pipeline", steps=6, replicas=4, model="bert-tiny", examples=256)
+    res = run_distributed(W.gpu_pipeline_recipe, 8, args=("pipeline", False, "bert-tiny", True, 256))
+    got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
+    assert len(got) == len(ref) == 6, (got, ref)
+    assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+    assert all(r["replicas_bit_equal"] is True for r in res)
+
+
 def test_rccl_call_path_single_rank():
     """A 1-rank "nccl" (= RCCL) group with forced collectives: broadcast, bucketed all-reduce with the native
     AVG reduction on the communicator's stream, barrier - the API path the multi-GPU runs take."""
