@@ -127,27 +127,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // combine the block's 4 waves: LDS [4][3][H + H/8] fp32.  A lane owns 8 consecutive columns per chunk, so its
-  // stores are 8 floats apart; one pad word per chunk (column c*8+j at word c*9+j) spreads the 32 lanes of a store
-  // over 32 banks instead of 4.
+  // combine the block's 4 waves: LDS [4][3][H + H/32] fp32.  A lane owns 8 consecutive columns per chunk, so its
+  // stores are 8 floats apart; one pad word per 32 columns (column x at word x + x/32) spreads the 32 lanes of a store
+  // over 32 banks instead of 4, and keeps the block at 49.5 KiB for H = 1024: three blocks per CU (a pad word per
+  // chunk made it 54 KiB, two blocks per CU, and the kernel 48 % slower).
   float* red = reinterpret_cast<float*>(smem);
-  const int HP = H + nchunk;
+  const int HP = H + (H >> 5);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        red[(wave * 3 + 0) * HP + c * 9 + j] = pg[i][j];
-        red[(wave * 3 + 1) * HP + c * 9 + j] = pb[i][j];
-        red[(wave * 3 + 2) * HP + c * 9 + j] = pd[i][j];
+        red[(wave * 3 + 0) * HP + c * 8 + (c >> 2) + j] = pg[i][j];
+        red[(wave * 3 + 1) * HP + c * 8 + (c >> 2) + j] = pb[i][j];
+        red[(wave * 3 + 2) * HP + c * 8 + (c >> 2) + j] = pd[i][j];
       }
     }
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < 3 * H; idx += 256) {
     const int seg = idx / H, col = idx - seg * H;
-    const int w = seg * HP + col + (col >> 3);
+    const int w = seg * HP + col + (col >> 5);
     const float s = red[w] + red[3 * HP + w] + red[6 * HP + w] + red[9 * HP + w];
     partial[(size_t)blockIdx.x * 3 * H + idx] = s;
   }
@@ -273,7 +274,7 @@ extern "C" int pdt_layernorm_bwd(int dtype, const void* dy, const void* x, const
   int nb = (rows + rpw - 1) / rpw;
   nb = nb < 1 ? 1 : (nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   *nblk = nb;
-  const size_t lds = (size_t)4 * 3 * (H + H / 8) * sizeof(float);
+  const size_t lds = (size_t)4 * 3 * (H + H / 32) * sizeof(float);
   // registers are sized for the row length: 1 / 2 / 4 chunks of 8 elements per lane (H <= 512 / 1024 / 2048)
 #define PDT_LNB(TT, NCH)                                                                                          \
   do {                                                                                                            \
