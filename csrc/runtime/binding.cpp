@@ -484,6 +484,60 @@ Tensor layer_backward(const Tensor& dy_in, const Tensor& x, const std::vector<Te
 }
 
 // ---------------------------------------------------------------------------------------------------
+// A run of encoder layers as ONE call (one autograd node per stack instead of one per layer): with short
+// micro-batches the host, not the GPU, bounds a step, and the Python / autograd round trip per layer is a fifth
+// of the host time of a layer.  `layer_ids`: dropout site base of every layer.  Forward returns, per layer, the 11
+// tensors of layer_forward (output first); the input of layer l > 0 is the output of layer l-1.
+// ---------------------------------------------------------------------------------------------------
+std::vector<Tensor> stack_forward(const Tensor& x, const Tensor& mask, const Tensor& kv_len,
+                                  const std::vector<std::vector<Tensor>>& w, const Tensor& rng_state, int64_t B, int64_t S,
+                                  int64_t A, double p_attn, double p_hidden, double eps, int64_t micro,
+                                  const std::vector<int64_t>& layer_ids, const OptTensor& sids, const OptTensor& cu,
+                                  const OptTensor& rowmap) {
+  TORCH_CHECK(!w.empty() && w.size() == layer_ids.size(), "stack_forward: one weight list and one id per layer");
+  std::vector<Tensor> all;
+  all.reserve(w.size() * 11);
+  Tensor h = x;
+  for (size_t l = 0; l < w.size(); ++l) {
+    std::vector<Tensor> o = layer_forward(h, mask, kv_len, w[l], rng_state, B, S, A, p_attn, p_hidden, eps, micro,
+                                          layer_ids[l], sids, cu, rowmap);
+    h = o[0];
+    for (auto& t : o) all.push_back(std::move(t));
+  }
+  return all;
+}
+
+// Backward of the run, last layer first.  `saved[l]` = the 11 tensors stack_forward returned for layer l;
+// `accumulate[l]`: add to layer l's gradients instead of overwriting them.  After every layer its saved tensors
+// are dropped and `layer_done(l)` is called with the GIL held (the Python side drops ITS references there and
+// reports the layer's gradient segment as complete: bucket all-reduce, gradient-lane merge).
+Tensor stack_backward(const Tensor& dy_in, const Tensor& x0, std::vector<std::vector<Tensor>> saved, const Tensor& mask,
+                      const Tensor& kv_len, const std::vector<std::vector<Tensor>>& w,
+                      const std::vector<std::vector<Tensor>>& gr, const Tensor& rng_state, int64_t B, int64_t S, int64_t A,
+                      double p_attn, double p_hidden, int64_t micro, const std::vector<int64_t>& layer_ids,
+                      const std::vector<int64_t>& accumulate, const OptTensor& sids, const OptTensor& cu,
+                      const OptTensor& rowmap, py::handle layer_done) {
+  const size_t L = w.size();
+  TORCH_CHECK(L > 0 && saved.size() == L && gr.size() == L && layer_ids.size() == L && accumulate.size() == L,
+              "stack_backward: per-layer lists of different lengths");
+  Tensor dy = dy_in;
+  for (size_t i = L; i-- > 0;) {
+    TORCH_CHECK(saved[i].size() == 11, "stack_backward: 11 saved tensors per layer expected");
+    const Tensor& xin = i == 0 ? x0 : saved[i - 1][0];
+    std::vector<Tensor> sv(saved[i].begin() + 1, saved[i].end());
+    dy = layer_backward(dy, xin, sv, mask, kv_len, w[i], gr[i], rng_state, B, S, A, p_attn, p_hidden, micro, layer_ids[i],
+                        accumulate[i] != 0, sids, cu, rowmap);
+    sv.clear();
+    saved[i].clear();
+    if (!layer_done.is_none()) {
+      py::gil_scoped_acquire gil;
+      layer_done((int64_t)i);
+    }
+  }
+  return dy;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Embeddings
 // ---------------------------------------------------------------------------------------------------
 std::vector<Tensor> embed_forward(const c10::optional<Tensor>& ids, const Tensor& pos_ids, const Tensor& type_ids,
@@ -769,6 +823,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   using nogil = py::call_guard<py::gil_scoped_release>;
   m.def("layer_forward", &layer_forward, nogil());
   m.def("layer_backward", &layer_backward, nogil());
+  m.def("stack_forward", &stack_forward, nogil());
+  m.def("stack_backward", &stack_backward, nogil());
   m.def("embed_forward", &embed_forward, nogil());
   m.def("embed_backward", &embed_backward, nogil());
   m.def("dense_tanh_forward", &dense_tanh_forward, nogil());

@@ -205,15 +205,15 @@ class Engine:
         """Forward + backward of one accumulation window (`batches` = its micro-batches, loss / len(batches) each, the
         gradient all-reduce armed for the last one only); returns the detached per-micro-batch losses.
 
-        With ``overlap`` (default: on for the native GPU path) the window is software-pipelined over two HIP
-        streams: the forward of micro-batch i+1 is enqueued before the backward of micro-batch i and runs next to
-        it.  The two are independent - the weights only change at the optimizer step - and with the reference's
+        With ``overlap`` (default: on for the native GPU path) the window is software-pipelined over three HIP
+        streams (micro-batch i on stream i % 3): the forward passes of the next micro-batches are enqueued before the
+        backward of micro-batch i and run next to it.  The two are independent - the weights only change at the optimizer step - and with the reference's
         8-sample micro-batches (/root/reference/test_data_parallelism.py:90-93) neither fills the GPU on its own:
         a 1024-token GEMM has 64-256 output tiles for 256 CUs.  Every micro-batch lives on ONE stream (forward
         and backward, which is also where autograd runs a node's backward); even and odd micro-batches accumulate
         into two gradient buffers that the last backward merges (``PDT_DUAL_BACKWARD=0``: into one buffer, with the
         backward passes ordered by events - bit-identical to the plain loop), and the caller's stream waits for
-        both streams before the optimizer step."""
+        the other streams before the optimizer step."""
         n = len(batches)
         dp = model if isinstance(model, DataParallel) else None
         if overlap is None:
@@ -234,16 +234,25 @@ class Engine:
                     losses.append(out.loss.detach())
                 return losses
             main = torch.cuda.current_stream(self.device)
-            if getattr(self, "_alt_stream", None) is None:
-                self._alt_stream = torch.cuda.Stream(device=self.device)
-            streams = [main, self._alt_stream]
+            # micro-batch i lives on stream i % ns (PDT_MICRO_STREAMS, default 3: the caller's stream and two more).
+            # Measured at 12 x 8 samples of BERT-large: 2 streams 1455 samples/s, 3 streams 1571, 4 streams 1357 - with
+            # the weight-gradient side stream, 3 streams use exactly the 4 hardware queues a process gets, a fifth
+            # stream shares one and serialises behind it.
+            ns = max(2, min(n, int(os.environ.get("PDT_MICRO_STREAMS", "3"))))
+            if getattr(self, "_alt_streams", None) is None:
+                self._alt_streams = []
+            while len(self._alt_streams) < ns - 1:
+                self._alt_streams.append(torch.cuda.Stream(device=self.device))
+            streams = [main] + self._alt_streams[:ns - 1]
             start = torch.cuda.Event()
             start.record(main)
-            self._alt_stream.wait_event(start)  # parameters / batches produced on the caller's stream so far
-            for b in batches[1::2]:
-                for t in b.values():
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(self._alt_stream)
+            for st in streams[1:]:
+                st.wait_event(start)  # parameters / batches produced on the caller's stream so far
+            for i, b in enumerate(batches):
+                if i % ns:
+                    for t in b.values():
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(streams[i % ns])
             # Two gradient lanes (default; PDT_DUAL_BACKWARD=0 keeps one): micro-batch i accumulates into lane i % 2, a gradient buffer of
             # its own, so the backward passes of the two streams need no ordering between them and each stream runs its
             # micro-batches (forward, backward, forward, ...) independently of the other.  The last backward of the
@@ -256,7 +265,7 @@ class Engine:
                 rt.arena.enable_alt()
 
             def forward(i):
-                with torch.cuda.stream(streams[i % 2]):
+                with torch.cuda.stream(streams[i % ns]):
                     if dual:
                         rt.lane = i % 2  # (captured by the nodes of this forward pass; one forward runs at a time)
                     out = model(**batches[i])
@@ -282,18 +291,32 @@ class Engine:
             # backward still cost 25 runtime calls on the host)
             if os.environ.get("PDT_OVERLAP_SPLITK", "1") == "0":
                 _native().set_gemm_split_k(False)
-            cur, done = forward(0), [None, None]
+            # How far the forward thread runs ahead of the backward passes (PDT_FWD_AHEAD, default 2): forward(i+2) is
+            # queued - on the stream of micro-batch i, behind or between the kernels of backward(i), which it does not
+            # depend on - while the host is still issuing backward(i).  With a distance of 1 both streams ran dry for
+            # ~0.45 ms at the end of every backward pass (its host thread had to start the next forward AND the next
+            # backward from an empty queue): 12 gaps per 12 x 8 step.
+            ahead = max(1, int(os.environ.get("PDT_FWD_AHEAD", "2"))) if threaded else 1
+            cur, done = forward(0), [None] * n
+            queued = {}
+            for j in range(1, min(n, ahead)):  # (forward(i + ahead) is submitted at the top of iteration i)
+                queued[j] = self._fwd_pool.submit(forward, j)
             for i in range(n):
                 nxt = None
-                if i + 1 < n:  # started BEFORE backward(i): runs concurrently with it
-                    nxt = self._fwd_pool.submit(forward, i + 1) if threaded else forward(i + 1)
-                s = streams[i % 2]
+                if threaded:
+                    if i + ahead < n:
+                        queued[i + ahead] = self._fwd_pool.submit(forward, i + ahead)
+                    nxt = queued.pop(i + 1, None)
+                elif i + 1 < n:  # started BEFORE backward(i): runs concurrently with it
+                    nxt = forward(i + 1)
+                s = streams[i % ns]
                 with torch.cuda.stream(s):
-                    other = done[(i + 1) % 2]
-                    if other is not None and (not dual or i == n - 1):
+                    if i >= 1 and (not dual or i == n - 1):
                         # one lane: backward passes accumulate into one buffer, strictly one after the other;
-                        # two lanes: only the merging (last) backward has to see the other stream's gradients
-                        s.wait_event(other)
+                        # two lanes: only the merging (last) backward has to see the other lane's gradients
+                        s.wait_event(done[i - 1])
+                    if dual and ns > 2 and i >= 2:
+                        s.wait_event(done[i - 2])  # (the previous backward of this lane ran on another stream)
                     if dp is not None:
                         dp.require_sync = i == n - 1
                         if i == n - 1:
@@ -316,15 +339,16 @@ class Engine:
                             _native().wgrad_join()
                     if dual and i == n - 1:
                         rt.arena.merge_alt()  # (segments that no node of the last backward reported)
-                    done[i % 2] = torch.cuda.Event()
-                    done[i % 2].record(s)
+                    done[i] = torch.cuda.Event()
+                    done[i].record(s)
                 losses.append(cur[0].loss.detach())
                 cur = nxt.result() if (threaded and nxt is not None) else nxt
             if dual:
                 rt.lane = 0
-            tail = torch.cuda.Event()  # the caller's stream continues after everything on the second stream
-            tail.record(self._alt_stream)
-            main.wait_event(tail)
+            for st in streams[1:]:  # the caller's stream continues after everything on the other streams
+                tail = torch.cuda.Event()
+                tail.record(st)
+                main.wait_event(tail)
             return losses
         finally:
             if split_k is not None:

@@ -265,8 +265,14 @@ class BertEncoder(nn.Module):
             if m is not None and m.dim() == 4:
                 m = (m[:, 0, 0, :] == 0).to(torch.int32)
             mask_info = MaskInfo(m, b, s, hidden_states.device)
+        layers = self.layers()
+        if (not output_hidden_states and hidden_states.is_cuda and layers
+                and all(l._native is not None for l in layers)):
+            from ..ops import fused
+
+            return (fused.encoder_stack_forward(layers, hidden_states, mask_info, rng), None)
         all_h = [hidden_states] if output_hidden_states else None
-        for lyr in self.layers():
+        for lyr in layers:
             hidden_states = lyr(hidden_states, mask_info, rng)
             if output_hidden_states:
                 all_h.append(hidden_states)
@@ -409,8 +415,7 @@ class _ClassifierBase(nn.Module):
             x = fused.embeddings_forward_packed(emb, ids, types, pos, rowmap, inputs_embeds)
         else:
             x = hidden_states
-        for lyr in base.encoder.layers():
-            x = fused.encoder_layer_forward(lyr, x, mask)
+        x = fused.encoder_stack_forward(base.encoder.layers(), x, mask)
         if not (run_head and getattr(self, "with_head", False)):
             return SequenceClassifierOutput(last_hidden_state=x)
         first = x.index_select(0, cu[:-1].to(torch.int64)).unsqueeze(1)  # token 0 of every sample: [B, 1, H]

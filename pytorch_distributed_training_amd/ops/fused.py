@@ -8,6 +8,7 @@ all-reduce of a layer while backward is still running on the layers below it.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -184,6 +185,76 @@ def encoder_layer_forward(layer, hidden, mask, rng=None):
         # input arrived from the previous rank): parameter gradients are produced inside backward()
         hidden = hidden.detach().requires_grad_()
     return _LayerFn.apply(hidden.contiguous(), layer, mask)
+
+
+class _StackFn(torch.autograd.Function):
+    """A run of encoder layers as one autograd node (csrc: stack_forward / stack_backward).  Same kernels, same
+    dropout keys, same gradient-segment bookkeeping as a chain of _LayerFn nodes - the per-layer work that needs
+    Python (accumulate flags, the segment-done callback of the data-parallel reducer) is done before resp. from
+    inside the one C++ call."""
+
+    @staticmethod
+    def forward(ctx, x, layers, mask):
+        first = layers[0]
+        cfg = first.cfg
+        packed = mask.cu is not None
+        B, S, H = (mask.batch, mask.seq, x.shape[-1]) if packed else x.shape
+        m, kvl = mask.native()
+        train = first.training
+        key = first._native.rt.key
+        x2 = x if packed else x.reshape(B * S, H)
+        ids = [l.index + l._native.site_offset for l in layers]
+        outs = native().stack_forward(
+            x2, m, kvl, [l._native.w for l in layers], key.state, B, S, cfg.num_attention_heads,
+            cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
+            cfg.layer_norm_eps, key.counter, ids, key.sample_ids, mask.cu, mask.rowmap)
+        ctx.layers, ctx.mask, ctx.x2, ctx.ids = layers, (m, kvl, mask.cu, mask.rowmap), x2, ids
+        ctx.saved = [outs[i * 11:(i + 1) * 11] for i in range(len(layers))]
+        ctx.meta = (B, S, H, train, key, packed)
+        ctx.lane = first._native.rt.lane
+        y = outs[-11]
+        return y if packed else y.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        layers = ctx.layers
+        cfg = layers[0].cfg
+        rt = layers[0]._native.rt
+        B, S, H, train, key, packed = ctx.meta
+        lane = ctx.lane
+        acc = [int(l._native.arena.take_accumulate_flag(l._native.segment, lane)) for l in layers]
+        saved, ctx.saved = ctx.saved, None
+
+        def layer_done(i: int) -> None:
+            saved[i] = None
+            rt.done(layers[i]._native.segment)
+
+        dx = native().stack_backward(
+            dy.reshape(-1, H), ctx.x2, saved, ctx.mask[0], ctx.mask[1], [l._native.w for l in layers],
+            [l._native.grads(lane) for l in layers], key.state, B, S, cfg.num_attention_heads,
+            cfg.attention_probs_dropout_prob if train else 0.0, cfg.hidden_dropout_prob if train else 0.0,
+            key.counter, ctx.ids, acc, key.sample_ids, ctx.mask[2], ctx.mask[3], layer_done)
+        ctx.x2 = None
+        return (dx if packed else dx.view(B, S, H)), None, None
+
+
+def encoder_stack_forward(layers, hidden, mask, rng=None):
+    """`layers` (consecutive BertLayer modules adopted by one arena) applied to `hidden` as one autograd node;
+    PDT_LAYER_NODES=1 keeps one node per layer."""
+    if not layers:
+        return hidden
+    if len(layers) == 1 or os.environ.get("PDT_LAYER_NODES") == "1":
+        for lyr in layers:
+            hidden = encoder_layer_forward(lyr, hidden, mask, rng)
+        return hidden
+    nat = layers[0]._native
+    if hidden.dtype != nat.w[0].dtype:
+        hidden = hidden.to(nat.w[0].dtype)
+    if hidden.dim() == 2 and mask.cu is None:
+        raise ValueError("2-D hidden states are the packed rows of an unpadded batch: the mask must carry cu_seqlens")
+    if not hidden.requires_grad and torch.is_grad_enabled():
+        hidden = hidden.detach().requires_grad_()  # (see encoder_layer_forward)
+    return _StackFn.apply(hidden.contiguous(), layers, mask)
 
 
 # --------------------------------------------------------------------------------------------------
