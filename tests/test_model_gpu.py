@@ -607,3 +607,45 @@ def test_micro_batch_cap_is_sized_for_the_hbm_of_this_gpu():
     assert TrainConfig().accumulation(dev, large) == (1, 96)
     assert TrainConfig(max_length=128).micro_batch_cap(dev, large) <= 1024
     assert TrainConfig(max_gpu_batch_size=8).accumulation(dev, large) == (12, 8)
+
+
+@pytest.mark.parametrize("streams", ["2", "4"])
+def test_encoder_stack_as_one_autograd_node_equals_one_node_per_layer(monkeypatch, streams):
+    """The run of encoder layers is ONE autograd node by default (stack_forward / stack_backward issue every layer from
+    C++ and report each layer's gradient segment from inside the call); PDT_LAYER_NODES=1 keeps a node per layer.  Same
+    kernels in the same order: losses, accumulated gradients and weights after three optimizer steps are bit-identical,
+    also with the accumulation window spread over 2 or 4 streams instead of the default 3."""
+    from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+    from pytorch_distributed_training_amd.engine import Engine
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.optim import AdamW
+
+    monkeypatch.setenv("PDT_DUAL_BACKWARD", "0")
+
+    def run(per_layer, ns):
+        monkeypatch.setenv("PDT_LAYER_NODES", "1" if per_layer else "0")
+        monkeypatch.setenv("PDT_MICRO_STREAMS", ns)
+        torch.manual_seed(3)
+        eng = Engine(fp16=True, seed=11, init_scale=1024.0)
+        model = build_model("bert-tiny")
+        opt = AdamW(params=model.parameters(), lr=1e-3)
+        model, opt = eng.prepare(model, opt)
+        model.train()
+        batches = [fixed_batch(4, 32, 512, eng.device, seed=70 + i, first_id=4 * i) for i in range(5)]
+        losses, grads = [], None
+        for step in range(3):
+            ls = eng.accumulate(model, batches, overlap=True)
+            torch.cuda.synchronize()
+            if step == 0:
+                grads = model.arena.grad.clone()
+            losses += [float(x) for x in ls]
+            opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        return losses, grads, model.arena.master.clone()
+
+    l0, g0, m0 = run(True, "3")
+    l1, g1, m1 = run(False, "3")
+    l2, g2, m2 = run(False, streams)
+    assert g0.abs().sum() > 0 and l0 == l1 == l2
+    assert torch.equal(g0, g1) and torch.equal(m0, m1)
+    assert torch.equal(g0, g2) and torch.equal(m0, m2)
