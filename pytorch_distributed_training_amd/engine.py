@@ -235,9 +235,10 @@ class Engine:
                 return losses
             main = torch.cuda.current_stream(self.device)
             # micro-batch i lives on stream i % ns (PDT_MICRO_STREAMS, default 3: the caller's stream and two more).
-            # Measured at 12 x 8 samples of BERT-large: 2 streams 1455 samples/s, 3 streams 1571, 4 streams 1357 - with
-            # the weight-gradient side stream, 3 streams use exactly the 4 hardware queues a process gets, a fifth
-            # stream shares one and serialises behind it.
+            # Measured at 12 x 8 samples of BERT-large: 2 streams 1455 samples/s, 3 streams 1571, 4 streams 1357 (1057
+            # when the process gets 8 hardware queues instead of the default 4, GPU_MAX_HW_QUEUES=8, i.e. when the
+            # fourth chain really runs concurrently): the GEMMs of these micro-batches hold 96-128 KiB of LDS, one
+            # workgroup per CU, and a fourth chain of them only queues for CUs and evicts the others' operands.
             ns = max(2, min(n, int(os.environ.get("PDT_MICRO_STREAMS", "3"))))
             if getattr(self, "_alt_streams", None) is None:
                 self._alt_streams = []
