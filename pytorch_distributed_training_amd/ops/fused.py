@@ -243,7 +243,9 @@ def encoder_stack_forward(layers, hidden, mask, rng=None):
     PDT_LAYER_NODES=1 keeps one node per layer."""
     if not layers:
         return hidden
-    if len(layers) == 1 or os.environ.get("PDT_LAYER_NODES") == "1":
+    # (without a tape - evaluation - the layers run one by one: every layer's saved tensors die with its call, whereas the
+    # one-call form returns those of the whole stack at once)
+    if len(layers) == 1 or not torch.is_grad_enabled() or os.environ.get("PDT_LAYER_NODES") == "1":
         for lyr in layers:
             hidden = encoder_layer_forward(lyr, hidden, mask, rng)
         return hidden
