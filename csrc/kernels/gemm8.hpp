@@ -23,6 +23,9 @@
 #include "gemm.hpp"
 
 // PDT_ABLATE (bench/micro/gemm8_ablate.hip only): compile parts of a phase out to see what bounds the loop
+#ifndef PDT_GROUP_M8
+#define PDT_GROUP_M8 8  // tile rows per rasterisation group of this kernel (see tile_coords)
+#endif
 #ifndef PDT_ABLATE
 #define PDT_ABLATE 0
 #endif
@@ -88,7 +91,7 @@ struct Gemm8 {
     int nxt = (persistent && (int)(blockIdx.x >> 3) + per_xcd < xcd_count) ? cur + per_xcd : -1;
     auto locate = [&](int id, int& tm_, int& tn_, int& split_) {
       split_ = id / ntiles;
-      tile_coords(id - split_ * ntiles, g.tiles_m, g.tiles_n, tm_, tn_);
+      tile_coords<PDT_GROUP_M8>(id - split_ * ntiles, g.tiles_m, g.tiles_n, tm_, tn_);
     };
     LoaderA la0, la1;
     LoaderB lb0, lb1;
