@@ -293,10 +293,10 @@ class Engine:
             if os.environ.get("PDT_OVERLAP_SPLITK", "1") == "0":
                 _native().set_gemm_split_k(False)
             # How far the forward thread runs ahead of the backward passes (PDT_FWD_AHEAD, default 2): forward(i+2) is
-            # queued - on the stream of micro-batch i, behind or between the kernels of backward(i), which it does not
-            # depend on - while the host is still issuing backward(i).  With a distance of 1 both streams ran dry for
-            # ~0.45 ms at the end of every backward pass (its host thread had to start the next forward AND the next
-            # backward from an empty queue): 12 gaps per 12 x 8 step.
+            # queued while the host is still issuing backward(i), which it does not depend on.  With a distance of 1 a
+            # rocprofv3 trace (where every launch costs the host more) shows all streams running dry for ~0.45 ms at the
+            # end of every backward pass - the host then has to start the next forward AND the next backward from empty
+            # queues; unprofiled, the 12 x 8 step measures the same with 1 and 2 (the GPU is the bound there).
             ahead = max(1, int(os.environ.get("PDT_FWD_AHEAD", "2"))) if threaded else 1
             cur, done = forward(0), [None] * n
             queued = {}
