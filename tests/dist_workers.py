@@ -317,7 +317,7 @@ def gpu_dp_comm_fallback(rank, world):
     return out
 
 
-def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True, examples=64):
+def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True, examples=64, lr=2e-3):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
@@ -326,7 +326,7 @@ def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodro
 
         os.environ["PDT_DEBUG"] = "1"
     cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2,
-                      batch_size=16, max_gpu_batch_size=4, lr=2e-3, num_warmup_steps=1, log_every=1, max_steps=6,
+                      batch_size=16, max_gpu_batch_size=4, lr=lr, num_warmup_steps=1, log_every=1, max_steps=6,
                       seed=5, mp_layout=layout, init_scale=256.0, varlen=varlen)
     if layout == "towers":
         cfg.batch_size, cfg.max_gpu_batch_size = 8, 8
@@ -367,7 +367,7 @@ def gpu_dp_dropout(rank, world, steps=6):
     return losses
 
 
-def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", examples=64):
+def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", examples=64, lr=2e-3):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
     from pytorch_distributed_training_amd.models.tribert import TriBert
@@ -385,7 +385,7 @@ def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", 
     set_seed(5)
     torch.manual_seed(5)
     model = TriBert(build_model(mc), build_model(mc), build_model(mc)) if layout == "towers" else build_model(mc)
-    opt = AdamW(params=model.parameters(), lr=2e-3)
+    opt = AdamW(params=model.parameters(), lr=lr)
     model, opt, dl = eng.prepare(model, opt, dl)
     sched = get_linear_schedule_with_warmup(opt, 1, len(dl) * 2)
     losses = []
