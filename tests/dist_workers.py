@@ -333,7 +333,7 @@ def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodro
     return run_model_parallel(rank, world, cfg)
 
 
-def gpu_dp_dropout(rank, world, steps=6):
+def gpu_dp_dropout(rank, world, steps=6, model="bert-tiny", examples=64, lr=2e-3):
     """Data-parallel native fp16 training WITH dropout; the logged loss is the mean over the ranks' shards."""
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
@@ -341,16 +341,16 @@ def gpu_dp_dropout(rank, world, steps=6):
     from pytorch_distributed_training_amd.recipes import _collator, build_datasets
     from pytorch_distributed_training_amd.utils.seed import set_seed
 
-    cfg = TrainConfig(model="bert-tiny", fp16=True, train_examples=64, eval_examples=16, num_epochs=2, batch_size=8, seed=5)
+    cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2, batch_size=8, seed=5)
     eng = Engine(fp16=True, seed=5, init_scale=256.0, min_bucket_mb=0.05)
     mc = preset(cfg.model)
     train_ds, _ = build_datasets(cfg, mc)
     dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=8)
     set_seed(5)
     torch.manual_seed(5)
-    model = build_model(mc)
-    opt = AdamW(params=model.parameters(), lr=2e-3)
-    model, opt, dl = eng.prepare(model, opt, dl)
+    net = build_model(mc)
+    opt = AdamW(params=net.parameters(), lr=lr)
+    model, opt, dl = eng.prepare(net, opt, dl)
     sched = get_linear_schedule_with_warmup(opt, 1, len(dl) * 2)
     losses = []
     model.train()
