@@ -44,6 +44,7 @@ class TrainConfig:
     bf16: bool = False
     cpu: bool = False
     init_scale: float = 65536.0  # initial dynamic loss scale of fp16 runs (torch GradScaler's default)
+    max_grad_norm: float = 0.0   # > 0: clip the global gradient norm before every optimizer step (the reference does not)
     # data (no hub access: synthetic MRPC-shaped pairs unless a local TSV directory is given)
     data_dir: Optional[str] = None
     vocab_file: Optional[str] = None

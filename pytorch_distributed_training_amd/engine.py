@@ -192,6 +192,35 @@ class Engine:
             loss = loss * self.scaler.scale_tensor().to(loss.dtype)
         loss.backward(**kw)
 
+    def clip_grad_norm_(self, model: nn.Module, max_norm: float, group=None) -> torch.Tensor:
+        """Scale the gradients of `model` so that their global L2 norm is at most `max_norm` (Accelerate's
+        ``clip_grad_norm_``; the reference never clips, so the recipes only call this with ``--max-grad-norm``).
+        Returns the norm before clipping, un-scaled, as a 0-d tensor; nothing is read back to the host.
+
+        Models adopted into an arena are clipped on the flat gradient: one norm and one multiply over the arena, with
+        the loss scale divided out of the norm on the device.  Call it after the last backward of a step - in a
+        data-parallel run the gradients are reduced by then and every replica computes the same factor.  `group`: ranks
+        that hold disjoint parts of one model (the stages of a pipeline replica) - their squared norms are summed.
+        A non-finite gradient gives a non-finite norm and leaves non-finite values in the arena, which the optimizer's
+        overflow check skips as before."""
+        inner = self.unwrap_model(model)
+        arena = getattr(inner, "arena", None)
+        if arena is None:
+            params = [p for p in inner.parameters() if p.grad is not None]
+            return torch.nn.utils.clip_grad_norm_(params, max_norm)
+        sq = torch.linalg.vector_norm(arena.grad).pow(2)
+        if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if sq.is_cuda and dist.get_backend(group) == "gloo":  # single-GPU rehearsal: cross gloo through the host
+                host = sq.detach().cpu()
+                dist.all_reduce(host, group=group)
+                sq = host.to(sq.device)
+            else:
+                dist.all_reduce(sq, group=group)
+        norm = sq.sqrt() / self.scaler.scale_tensor()
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        arena.grad.mul_(coef)
+        return norm
+
     @contextlib.contextmanager
     def no_sync(self, model: Optional[nn.Module] = None):
         models = [model] if model is not None else self._models

@@ -348,6 +348,8 @@ def run_tower_training(rank: int, world_size: int, cfg) -> dict:
                 inner_dp.require_sync = fire
             loss, _ = tower_step(part, mesh, engine, batch, train=True)
             if fire:
+                if cfg.max_grad_norm > 0:  # (the two ranks of a replica hold disjoint parameters)
+                    engine.clip_grad_norm_(part, cfg.max_grad_norm, group=mesh.pp_group)
                 optimizer.step(overflow_group=mesh.pp_group if engine.scaler.enabled else None)
                 sched.step()
                 optimizer.zero_grad()

@@ -243,7 +243,9 @@ class PipelineStage:
         return self.module(hidden_states=act, attention_mask=batch["attention_mask"], cu_seqlens=batch.get("cu_seqlens"),
                            token_index=batch.get("token_index")).logits
 
-    def optimizer_step(self, optimizer, scheduler=None) -> None:
+    def optimizer_step(self, optimizer, scheduler=None, max_grad_norm: float = 0.0) -> None:
+        if max_grad_norm > 0:  # the norm of the whole replica: squared norms of the two stages summed over the pair
+            self.engine.clip_grad_norm_(self.module, max_grad_norm, group=self.mesh.pp_group)
         optimizer.step(overflow_group=self.mesh.pp_group if self.engine.scaler.enabled else None)
         if scheduler is not None:
             scheduler.step()
@@ -329,7 +331,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
             train_dl.skip_batches(first)
         for index, batch in enumerate(train_dl, start=first):
             loss = pipe.train_step(batch)
-            pipe.optimizer_step(optimizer, sched)
+            pipe.optimizer_step(optimizer, sched, cfg.max_grad_norm)
             global_step += 1
             seed_step(cfg.seed, rank, global_step)
             dog.heartbeat()

@@ -197,6 +197,8 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
                     loss = torch.stack(engine.accumulate(model, pending)).mean() / window
             if fire:
                 with trace_range("optimizer"):
+                    if cfg.max_grad_norm > 0:
+                        engine.clip_grad_norm_(model, cfg.max_grad_norm)
                     optimizer.step()
                     lr_scheduler.step()
                     optimizer.zero_grad()

@@ -649,3 +649,30 @@ def test_encoder_stack_as_one_autograd_node_equals_one_node_per_layer(monkeypatc
     assert g0.abs().sum() > 0 and l0 == l1 == l2
     assert torch.equal(g0, g1) and torch.equal(m0, m1)
     assert torch.equal(g0, g2) and torch.equal(m0, m2)
+
+
+def test_clip_grad_norm_divides_the_loss_scale_out_on_the_device():
+    """fp16 with a loss scale: the returned norm is the un-scaled one, the clipped gradients have the requested
+    un-scaled norm, and an optimizer step after the clip moves the weights (no overflow is flagged by it)."""
+    from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+    from pytorch_distributed_training_amd.engine import Engine
+    from pytorch_distributed_training_amd.models.bert import build_model
+    from pytorch_distributed_training_amd.optim import AdamW
+
+    torch.manual_seed(0)
+    eng = Engine(fp16=True, seed=3, init_scale=1024.0)
+    model = build_model("bert-tiny")
+    opt = AdamW(params=model.parameters(), lr=1e-3)
+    model, opt = eng.prepare(model, opt)
+    model.train()
+    batch = fixed_batch(8, 32, model.config.vocab_size, eng.device, seed=1)
+    eng.backward(model(**batch).loss)
+    arena = model.arena
+    unscaled = (arena.grad.norm() / 1024.0).item()
+    got = eng.clip_grad_norm_(model, 0.25 * unscaled)
+    assert abs(got.item() - unscaled) < 1e-4 * unscaled
+    assert abs((arena.grad.norm() / 1024.0).item() - 0.25 * unscaled) < 1e-3 * unscaled
+    w0 = arena.master.clone()
+    opt.step(); opt.zero_grad()
+    torch.cuda.synchronize()
+    assert not eng.scaler.last_step_skipped() and not torch.equal(w0, arena.master)

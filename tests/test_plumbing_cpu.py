@@ -427,3 +427,31 @@ def test_native_extension_exports_runtime_switches():
     assert C.gemm_persistent_mode() == 0
     C.set_gemm_persistent(before)
     assert C.gemm_persistent_mode() == before
+
+
+def test_clip_grad_norm_on_the_flat_gradient_arena():
+    """Engine.clip_grad_norm_ scales the arena's gradient to the requested global norm (one norm, one multiply), returns
+    the norm before clipping, leaves gradients below the bound untouched, and the recipe flag reaches it."""
+    from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+    from pytorch_distributed_training_amd.engine import Engine
+    from pytorch_distributed_training_amd.optim import AdamW
+
+    torch.manual_seed(0)
+    eng = Engine(cpu=True)
+    model = build_model("bert-tiny")
+    opt = AdamW(params=model.parameters(), lr=1e-3)
+    model, opt = eng.prepare(model, opt)
+    model.train()
+    batch = fixed_batch(4, 16, model.config.vocab_size, eng.device, seed=1)
+    eng.backward(model(**batch).loss)
+    arena = eng.unwrap_model(model).arena
+    before = arena.grad.clone()
+    total = before.norm().item()
+    assert total > 0
+    got = eng.clip_grad_norm_(model, 10.0 * total)  # far above: nothing changes
+    assert abs(got.item() - total) < 1e-4 * total and torch.equal(arena.grad, before)
+    got = eng.clip_grad_norm_(model, 0.5 * total)
+    assert abs(got.item() - total) < 1e-4 * total
+    assert abs(arena.grad.norm().item() - 0.5 * total) < 1e-4 * total
+    assert torch.allclose(arena.grad, before * 0.5, rtol=1e-4, atol=1e-8)
+    assert parse_config(["--max-grad-norm", "1.0"]).max_grad_norm == 1.0 and TrainConfig().max_grad_norm == 0.0
