@@ -150,17 +150,17 @@ def dp_recipe(rank, world, tmp):
     return run_data_parallel(cfg)
 
 
-def pipeline_recipe(rank, world, micro_bs, accum, compat=False):
+def pipeline_recipe(rank, world, micro_bs, accum, compat=False, max_grad_norm=0.0):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
     cfg = TrainConfig(model="bert-tiny-nodrop", cpu=True, train_examples=64, eval_examples=16, num_epochs=2,
                       batch_size=micro_bs * accum, max_gpu_batch_size=micro_bs, lr=2e-3, num_warmup_steps=1,
-                      log_every=1, max_steps=6, seed=5, compat=compat)
+                      log_every=1, max_steps=6, seed=5, compat=compat, max_grad_norm=max_grad_norm)
     return run_model_parallel(rank, world, cfg)
 
 
-def single_process_reference(batch_size, steps=6):
+def single_process_reference(batch_size, steps=6, max_grad_norm=0.0):
     """Loss curve of ONE process on the whole global batch, same seed / data order / init as the pipeline runs."""
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
@@ -187,6 +187,8 @@ def single_process_reference(batch_size, steps=6):
         for batch in dl:
             loss = model(**batch).loss
             eng.backward(loss)
+            if max_grad_norm > 0:
+                eng.clip_grad_norm_(model, max_grad_norm)
             opt.step(); sched.step(); opt.zero_grad()
             losses.append(loss.item())
             if len(losses) >= steps:

@@ -90,6 +90,19 @@ def test_pipeline_loss_curve_matches_single_process():
     assert res[0]["accuracy"] == res[1]["accuracy"]
 
 
+def test_gradient_clipping_uses_the_norm_of_the_whole_replica():
+    """--max-grad-norm in the pipeline recipe: each stage holds half of the parameters, the squared norms are summed
+    over the pair, so the clipped run follows ONE process clipping the full model (a bound low enough to bind at
+    every step; with a norm per stage the curves part after the first update)."""
+    ref = W.single_process_reference(batch_size=16, max_grad_norm=0.05)
+    free = W.single_process_reference(batch_size=16)
+    assert max(abs(a - b) for a, b in zip(ref, free)) > 1e-3  # the bound binds
+    res = run_distributed(W.pipeline_recipe, 2, args=(4, 4, False, 0.05))
+    last = [r for r in res if r["stage"] == 1][0]
+    for a, b in zip(last["losses"], ref):
+        assert abs(a - b) < 2e-5, (last["losses"], ref)
+
+
 def test_dp_times_pipeline_loss_curve_matches_single_process():
     ref = W.single_process_reference(batch_size=16)
     res = run_distributed(W.pipeline_recipe, 4, args=(4, 2))  # 2 replicas x 2 stages, per-replica batch 8
