@@ -114,6 +114,34 @@ def load_pretrained(directory: str, num_labels: Optional[int] = None, **override
     return model
 
 
+def from_transformers(hf_model, **overrides) -> nn.Module:
+    """This framework's model from an in-memory ``transformers`` Bert / Roberta ``ForSequenceClassification`` (what the
+    reference builds with ``AutoModelForSequenceClassification.from_pretrained``,
+    /root/reference/test_data_parallelism.py:112): same configuration, same weights - parameter names are the HF names,
+    so the state dict is taken as it is."""
+    cfg = EncoderConfig.from_hf_dict(hf_model.config.to_dict())
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    model = build_model(cfg)
+    load_state_dict_into(model, {k: v.detach() for k, v in hf_model.state_dict().items()}, strict=True)
+    return model
+
+
+def to_transformers(model: nn.Module):
+    """The inverse of :func:`from_transformers`: a ``transformers`` model of the matching architecture holding this
+    model's (master, fp32) weights."""
+    import transformers
+
+    inner = _unwrap(model)
+    hf_cfg = transformers.AutoConfig.for_model(**inner.config.to_hf_dict())
+    hf = transformers.AutoModelForSequenceClassification.from_config(hf_cfg)
+    missing, unexpected = hf.load_state_dict(_hf_state_dict(model), strict=False)
+    missing = [k for k in missing if not k.endswith("position_ids")]  # (a buffer of some transformers versions)
+    if missing or unexpected:
+        raise KeyError(f"state dicts do not line up: missing {missing[:4]}, unexpected {list(unexpected)[:4]}")
+    return hf
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Training-state checkpoints.  Layout of `directory`:
 #

@@ -455,3 +455,25 @@ def test_clip_grad_norm_on_the_flat_gradient_arena():
     assert abs(arena.grad.norm().item() - 0.5 * total) < 1e-4 * total
     assert torch.allclose(arena.grad, before * 0.5, rtol=1e-4, atol=1e-8)
     assert parse_config(["--max-grad-norm", "1.0"]).max_grad_norm == 1.0 and TrainConfig().max_grad_norm == 0.0
+
+
+def test_in_memory_round_trip_with_a_transformers_model():
+    """checkpoint.from_transformers / to_transformers: a transformers model becomes this framework's model (same
+    configuration, same weights, same logits) and back, without going through files."""
+    from pytorch_distributed_training_amd import checkpoint as ckpt
+
+    hf = _hf_bert(build_model("bert-tiny").config)
+    ours = ckpt.from_transformers(hf).eval()
+    assert ours.config.hidden_size == hf.config.hidden_size and ours.config.num_hidden_layers == hf.config.num_hidden_layers
+    assert ours.config.hidden_dropout_prob == 0.0
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 512, (2, 12), generator=g)
+    mask = torch.ones(2, 12, dtype=torch.long); mask[1, 7:] = 0
+    with torch.no_grad():
+        a = ours(input_ids=ids, attention_mask=mask).logits
+        b = hf(input_ids=ids, attention_mask=mask).logits
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    back = ckpt.to_transformers(ours).eval()
+    with torch.no_grad():
+        c = back(input_ids=ids, attention_mask=mask).logits
+    torch.testing.assert_close(c, b, rtol=1e-4, atol=1e-5)
