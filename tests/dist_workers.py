@@ -319,7 +319,8 @@ def gpu_dp_comm_fallback(rank, world):
     return out
 
 
-def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True, examples=64, lr=2e-3):
+def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodrop", varlen=True, examples=64, lr=2e-3,
+                        init_scale=256.0):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.recipes import run_model_parallel
 
@@ -329,7 +330,7 @@ def gpu_pipeline_recipe(rank, world, layout, debug=False, model="bert-tiny-nodro
         os.environ["PDT_DEBUG"] = "1"
     cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2,
                       batch_size=16, max_gpu_batch_size=4, lr=lr, num_warmup_steps=1, log_every=1, max_steps=6,
-                      seed=5, mp_layout=layout, init_scale=256.0, varlen=varlen)
+                      seed=5, mp_layout=layout, init_scale=init_scale, varlen=varlen)
     if layout == "towers":
         cfg.batch_size, cfg.max_gpu_batch_size = 8, 8
     return run_model_parallel(rank, world, cfg)
@@ -369,7 +370,7 @@ def gpu_dp_dropout(rank, world, steps=6, model="bert-tiny", examples=64, lr=2e-3
     return losses
 
 
-def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", examples=64, lr=2e-3):
+def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", examples=64, lr=2e-3, init_scale=256.0):
     from pytorch_distributed_training_amd.config import TrainConfig
     from pytorch_distributed_training_amd.models.config import preset
     from pytorch_distributed_training_amd.models.tribert import TriBert
@@ -380,7 +381,7 @@ def gpu_single_reference(layout, steps=6, replicas=1, model="bert-tiny-nodrop", 
     bs = (8 if layout in ("towers", "dp") else 16) * replicas  # the global batch of `replicas` data-parallel replicas
     cfg = TrainConfig(model=model, fp16=True, train_examples=examples, eval_examples=16, num_epochs=2,
                       batch_size=bs, seed=5)
-    eng = Engine(fp16=True, seed=5, init_scale=256.0)
+    eng = Engine(fp16=True, seed=5, init_scale=init_scale)
     mc = preset(cfg.model)
     train_ds, _ = build_datasets(cfg, mc)
     dl = DataLoader(train_ds, shuffle=True, collate_fn=_collator(cfg, mc), batch_size=bs)

@@ -97,6 +97,18 @@ def test_dropout_masks_follow_the_sample_across_parallel_layouts():
     assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
 
 
+def test_pipeline_stages_skip_overflowed_steps_together():
+    """fp16 with a loss scale that overflows on the first steps (2^24 is halved several times before a gradient is finite):
+    the stages of a replica agree on every skip - the pipeline's loss curve is the one of a single process started with
+    the same scale, and differs from the curve of a run whose scale never overflows."""
+    ref = W.gpu_single_reference("pipeline", steps=6, replicas=1, init_scale=2.0 ** 24)
+    calm = W.gpu_single_reference("pipeline", steps=6, replicas=1)
+    assert max(abs(a - b) for a, b in zip(ref, calm)) > 1e-3, (ref, calm)  # updates were skipped
+    res = run_distributed(W.gpu_pipeline_recipe, 2, args=("pipeline", False, "bert-tiny-nodrop", True, 64, 2e-3, 2.0 ** 24))
+    got = [r for r in res if r["stage"] == 1][0]["losses"]
+    assert len(got) == 6 and max(abs(a - b) for a, b in zip(got, ref)) < 2e-2, (got, ref)
+
+
 def test_eight_ranks_as_four_pipeline_pairs_reproduce_the_single_process_loss_curve():
     """The layout of a whole node - 4 data-parallel replicas x 2 pipeline stages, rank = replica * 2 + stage
     (/root/reference/test_model_parallelism.py:244-253 on 8 devices) - rehearsed with 8 processes on the one GPU, fp16,
