@@ -191,6 +191,8 @@ def main() -> None:
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
             "final_loss": float(loss.item()) * args.accum,
             "tokens_per_s": round(value * args.seq_len, 1),
+            # model FLOPs (6 x linear-layer parameters + attention products, forward + backward) actually delivered per GPU
+            "model_tflops_per_gpu": round(value / world * _flops_per_sample(eng.unwrap_model(model).config, args.seq_len) / 1e12, 1),
             "comm_exposed_ms_per_step": exposed,
             "rccl_ranks": model.rccl_ranks() if hasattr(model, "rccl_ranks") else 0,
             "replicas_bit_equal": replicas_equal,
@@ -315,6 +317,7 @@ def bench_pipeline(args, world: int, comm) -> None:
             "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
             "final_loss": box[0], "tokens_per_s": round(value * args.seq_len, 1),
+            "model_tflops_per_gpu": round(value / world * _flops_per_sample(model_cfg, args.seq_len) / 1e12, 1),
             "comm_exposed_ms_per_step": round(exposed, 3) if exposed is not None else None,
             "rccl_ranks": stage.rccl_ranks() if hasattr(stage, "rccl_ranks") else 0,
             "pipeline_p2p": "rccl" if pipe.comm is not None else "c10d:" + dist.get_backend(),
@@ -328,6 +331,14 @@ def bench_pipeline(args, world: int, comm) -> None:
         }))
     dist.barrier()
     _teardown()
+
+
+def _flops_per_sample(cfg, seq: int) -> float:
+    """Training FLOPs of one sample of `seq` tokens: 6 per linear-layer parameter and token (forward + both backward
+    GEMMs), 12 * seq * hidden per token and layer for the two attention products, the pooler once per sample."""
+    L, H, F = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size
+    linear = L * (4 * H * H + 2 * H * F)
+    return seq * (6.0 * linear + 12.0 * L * seq * H) + 6.0 * H * H
 
 
 def _persist_mode() -> int:

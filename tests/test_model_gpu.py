@@ -294,6 +294,7 @@ def test_bench_contract_json_line():
     assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3 / 1000)) / d["value"] < 1e-2
     for key in ("model", "global_batch", "seq_len", "parallelism"):
         assert key in d["config"], key
+    assert d["model_tflops_per_gpu"] >= 0
 
 
 def test_data_parallel_recipe_end_to_end_single_gpu(tmp_path):
