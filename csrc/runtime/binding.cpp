@@ -6,6 +6,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/HIPEvent.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -298,6 +299,19 @@ void gemm_tn_into(const Tensor& A, const Tensor& B, Tensor& G, bool accumulate, 
   chk16(A, "A"); chk16(B, "B"); chkf32(G, "G");
   const int K = (int)A.size(0), M = (int)A.size(1), N = (int)B.size(1);
   TORCH_CHECK(B.size(0) == K && G.size(0) == M && G.size(1) == N, "gemm_tn: shape mismatch");
+  // The kernels address an operand through a 32-bit byte offset into a window that, for a weight gradient, spans the
+  // whole token range: more than ~2 GiB of either operand (e.g. 262144 tokens x 4096 columns) goes in token chunks,
+  // each added to the gradient.
+  const int64_t pitch = 2 * std::max<int64_t>(A.stride(0), B.stride(0));
+  const int64_t max_rows = ((int64_t)0x7FFF0000 / pitch - 1) / 64 * 64;
+  if (K > max_rows) {
+    TORCH_CHECK(max_rows >= 64, "gemm_tn: operand rows too long for the 32-bit window");
+    for (int64_t k0 = 0; k0 < K; k0 += max_rows) {
+      const int64_t len = std::min<int64_t>(max_rows, K - k0);
+      gemm_tn_into(A.narrow(0, k0, len), B.narrow(0, k0, len), G, accumulate || k0 > 0, tile, splits);
+    }
+    return;
+  }
   PdtGemm g{};
   g.A = A.data_ptr(); g.B = B.data_ptr();
   g.M = M; g.N = N; g.K = K;

@@ -720,3 +720,19 @@ def test_attention_unpadded_batch_equals_padded(smax):
                            None, sids)
     dq_u = C().op_attn_bwd(qkv, dummy, dummy, ctx_u, dctx, lse_u, B, S, A, st, 0.2, 3, 9, None, sids, cu)
     assert rel_err(dq_u.float(), dq_p[rows].float()) < 2e-3
+
+
+def test_gemm_tn_wgrad_over_more_tokens_than_one_operand_window():
+    """A weight gradient over 278528 tokens x 4096 columns: the 16-bit operand is 2.3 GB, beyond the 32-bit byte
+    offsets the kernels address a window with - the binding walks the token range in chunks that accumulate."""
+    torch.manual_seed(0)
+    T, M, N = 278528, 4096, 256
+    dY = (torch.randn(T, M, device="cuda") * 0.05).to(torch.float16)
+    X = (torch.randn(T, N, device="cuda") * 0.05).to(torch.float16)
+    G = C().op_gemm_tn(dY, X, None, False, -1, 0)
+    ref = torch.zeros(M, N, device="cuda")
+    for t0 in range(0, T, 32768):  # fp32 reference in slices (a full fp32 copy of dY would be 4.6 GB)
+        ref += dY[t0:t0 + 32768].float().t() @ X[t0:t0 + 32768].float()
+    assert rel_err(G, ref) < 2e-3
+    G2 = C().op_gemm_tn(dY, X, G.clone(), True, -1, 0)
+    assert rel_err(G2, 2 * ref) < 2e-3
