@@ -140,6 +140,13 @@ __device__ __forceinline__ uint32_t drop_row(const RngArgs& r, uint32_t row) {
   const uint32_t b = __umulhi(row, r.seq_magic);
   return (uint32_t)r.sample_ids[b] * 512u + (row - b * r.seq);
 }
+// p[idx] for a wave-uniform idx of a table no kernel of the step writes (sample ids): read through the constant
+// address space, i.e. as a scalar load (s_load_dword, lgkmcnt).  As a plain global load the compiler cannot prove
+// that the kernel's own stores leave the table alone and emits a vector load, whose s_waitcnt vmcnt(0) then also
+// waits for every output store in flight - in the GEMM epilogue four such round trips in a row per tile.
+__device__ __forceinline__ int32_t uniform_load_i32(const int32_t* p, uint32_t idx) {
+  return ((const __attribute__((address_space(4))) int32_t*)p)[idx];
+}
 __device__ __forceinline__ uint32_t drop_sample(const RngArgs& r, uint32_t b) {
   return r.sample_ids ? (uint32_t)r.sample_ids[b] : b;
 }

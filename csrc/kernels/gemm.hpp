@@ -213,7 +213,13 @@ struct GemmKernel {
   // before pair ip is processed, so their latency hides under the math and the LDS transpose; the bias is
   // read once; the column sums are kept in registers over the whole wave tile and stored once, into row `prow`
   // (tile row * 2 + wave row) of the partial-sum matrix.
-  template <int NIP, int epi, typename MBase>
+  // KEYMODE (BIAS_DROP_RES only): how a row's dropout row is found - 0: the row index itself (no sample ids, or
+  // dropout off), 1: row + a per-block offset from ONE scalar sample-id load (sequence length a multiple of 32),
+  // 2: a lookup per row (unpadded batches, other lengths).  A compile-time property of the copy: with the three ways
+  // behind run-time branches of one copy, the vector loads of mode 2 left `s_waitcnt vmcnt(0)` at the joins of every
+  // row iteration - which, executed on the paths of modes 0 and 1, waited for the output stores just issued, 16
+  // store round trips per tile.
+  template <int NIP, int epi, typename MBase, int KEYMODE = 0>
   static __device__ __forceinline__ void staged_epilogue_as(const GemmArgs& g, float4v (&acc)[2 * NIP][4], char* stg, int n,
                                                             MBase mbase, int prow, int lane) {
     const int lm = lane & 15, lg = lane >> 4, jc = lane & 7, rsub = lane >> 3;
@@ -230,8 +236,8 @@ struct GemmKernel {
     // sample-keyed dropout (PdtRng::sample_ids): when the sequence length is a multiple of 32 the 32 rows of a staged
     // block pair belong to ONE sample, so the id lookup is wave-uniform (a scalar load) and a row's dropout row is
     // m + offset; other lengths look the id up per row
-    const bool keyed = epi == EPI_BIAS_DROP_RES && g.drop_thr != 0 && (g.rng.sample_ids != nullptr || g.rng.row_table != nullptr);
-    const bool keyed_uniform = keyed && g.rng.row_table == nullptr && (g.rng.seq & 31u) == 0;
+    constexpr bool keyed = epi == EPI_BIAS_DROP_RES && KEYMODE != 0;
+    constexpr bool keyed_uniform = epi == EPI_BIAS_DROP_RES && KEYMODE == 1;
     auto fetch = [&](int ip, short8(&dst)[4]) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -249,7 +255,7 @@ struct GemmKernel {
         const uint32_t m32 = (uint32_t)__builtin_amdgcn_readfirstlane(mbase(ip));
         if (m32 < (uint32_t)g.M) {
           const uint32_t b = __umulhi(m32, g.rng.seq_magic);
-          drow_offs[ip] = (uint32_t)g.rng.sample_ids[b] * 512u - b * g.rng.seq;
+          drow_offs[ip] = (uint32_t)uniform_load_i32(g.rng.sample_ids, b) * 512u - b * g.rng.seq;
         }
       }
     }
@@ -307,7 +313,13 @@ struct GemmKernel {
       switch (g.epi) {
         case EPI_BIAS: return staged_epilogue_as<NIP, EPI_BIAS>(g, acc, stg, n, mbase, prow, lane);
         case EPI_BIAS_GELU: return staged_epilogue_as<NIP, EPI_BIAS_GELU>(g, acc, stg, n, mbase, prow, lane);
-        case EPI_BIAS_DROP_RES: return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES>(g, acc, stg, n, mbase, prow, lane);
+        case EPI_BIAS_DROP_RES: {
+          const bool keyed = g.drop_thr != 0 && (g.rng.sample_ids != nullptr || g.rng.row_table != nullptr);
+          if (!keyed) return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES, MBase, 0>(g, acc, stg, n, mbase, prow, lane);
+          if (g.rng.row_table == nullptr && (g.rng.seq & 31u) == 0)
+            return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES, MBase, 1>(g, acc, stg, n, mbase, prow, lane);
+          return staged_epilogue_as<NIP, EPI_BIAS_DROP_RES, MBase, 2>(g, acc, stg, n, mbase, prow, lane);
+        }
         case EPI_BIAS_TANH: return staged_epilogue_as<NIP, EPI_BIAS_TANH>(g, acc, stg, n, mbase, prow, lane);
         default: break;
       }
