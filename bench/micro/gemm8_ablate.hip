@@ -8,7 +8,26 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+// -DPDT_STAMPS=1: wave 0 of every workgroup records the constant-rate clock (10 ns ticks) at the boundaries of every
+// tile it computes (0 tile start, 1 K loop done, 2 wave groups re-aligned, 3 epilogue issued, 4 memory counter empty);
+// the harness prints the mean length of each section.  -DPDT_EPI=<PDT_EPI_* code>: run with that fused epilogue
+// (side inputs are random 16-bit tensors; dropout off).
+#ifndef PDT_STAMPS
+#define PDT_STAMPS 0
+#endif
+#if PDT_STAMPS
+#include <hip/hip_runtime.h>
+__device__ unsigned long long* pdt_stamp_buf;
+#define PDT_STAMP_MAXT 40
+// (stamps 0 and 1 also record the shader-cycle counter in slots 5 and 6: cycles / time of the K loop = the clock it ran at)
+#define PDT_STAMP(id) do { if (threadIdx.x == 0 && stamp_seq < PDT_STAMP_MAXT && pdt_stamp_buf != nullptr) { \
+  unsigned long long* q_ = pdt_stamp_buf + ((size_t)blockIdx.x * PDT_STAMP_MAXT + stamp_seq) * 8; \
+  q_[(id)] = wall_clock64(); if ((id) < 2) q_[5 + (id)] = __builtin_readcyclecounter(); } } while (0)
+#endif
 #include "../../csrc/kernels/gemm8.hpp"
+#ifndef PDT_EPI
+#define PDT_EPI PDT_EPI_PLAIN
+#endif
 
 #ifndef PDT_LAYOUT
 #define PDT_LAYOUT 0
@@ -31,7 +50,24 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
   PdtGemm g{};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = AKS ? M : K; g.ldb = BKS ? N : K; g.ldc = N;
-  g.epi = PDT_LAYOUT == 2 ? PDT_EPI_SLAB_F32 : PDT_EPI_PLAIN;
+  g.epi = PDT_LAYOUT == 2 ? PDT_EPI_SLAB_F32 : PDT_EPI;
+  if (g.epi != PDT_EPI_PLAIN && g.epi != PDT_EPI_SLAB_F32) {  // side inputs of the fused epilogues
+    std::vector<_Float16> hs((size_t)M * N);
+    for (auto& v : hs) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
+    _Float16 *S, *AUX, *BIAS;
+    CK(hipMalloc(&S, hs.size() * 2)); CK(hipMalloc(&AUX, hs.size() * 2)); CK(hipMalloc(&BIAS, (size_t)N * 2));
+    CK(hipMemcpy(S, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(AUX, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(BIAS, hs.data(), (size_t)N * 2, hipMemcpyHostToDevice));
+    g.bias = BIAS; g.res = S; g.ldr = N; g.aux = AUX; g.ldaux = N; g.drop_scale = 1.0f; g.drop_thr = 0;
+    if (getenv("PDT_DROP")) {  // dropout p = 0.1 with the row index as the dropout row
+      uint64_t hst[2] = {1234ull, 7ull}, *dst;
+      CK(hipMalloc(&dst, 16)); CK(hipMemcpy(dst, hst, 16, hipMemcpyHostToDevice));
+      g.rng.state = dst; g.rng.micro = 1; g.rng.stream = 5; g.drop_thr = 6554; g.drop_scale = 1.0f / 0.9f;
+    }
+  }
+  // argv[5]: 0 = the general epilogue everywhere, otherwise the straight-line epilogue for full tiles (needs 31-bit offsets)
+  g.fast_epi = (argc > 5 ? atoi(argv[5]) : 1) != 0 && (long long)M * N * 2 < 0x7FFFFFFFll;
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256; g.splits = splits;
   g.k_per_split = ((K / 64 + splits - 1) / splits) * 64;
   auto kern = pdt::gemm8_kernel<_Float16, AKS, BKS>;
@@ -45,6 +81,13 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> init(8, 2u * (grid / 8));
     CK(hipMalloc(&g.sync, 32)); CK(hipMemcpy(g.sync, init.data(), 32, hipMemcpyHostToDevice));
   }
+#if PDT_STAMPS
+  // the stamp buffer exists before the first launch: every launch of this build writes stamps
+  const size_t stamp_n = (size_t)grid * PDT_STAMP_MAXT * 8;
+  unsigned long long* sb; CK(hipMalloc(&sb, stamp_n * 8)); CK(hipMemset(sb, 0, stamp_n * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(pdt_stamp_buf), &sb, sizeof(sb)));
+  CK(hipDeviceSynchronize());
+#endif
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
   for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
@@ -56,7 +99,36 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
     if (ms / 10 < best) best = ms / 10;
   }
-  if (PDT_ABLATE == 0 && PDT_LAYOUT != 2) {  // spot check against the host: 64 random elements
+#if PDT_STAMPS
+  {
+    const size_t n = stamp_n;
+    CK(hipMemset(sb, 0, n * 8));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hsb(n);
+    CK(hipMemcpy(hsb.data(), sb, n * 8, hipMemcpyDeviceToHost));
+    double sum[5] = {0, 0, 0, 0, 0}, cyc = 0; long cnt = 0; unsigned long long t_first = ~0ull, t_last = 0;
+    for (int b = 0; b < grid; ++b)
+      for (int t = 0; t < PDT_STAMP_MAXT; ++t) {
+        const unsigned long long* q = &hsb[((size_t)b * PDT_STAMP_MAXT + t) * 8];
+        if (q[4] == 0) break;
+        if (q[0] < t_first) t_first = q[0];
+        if (q[4] > t_last) t_last = q[4];
+        if (t == 0) continue;  // (the first tile of a workgroup includes the prologue)
+        const unsigned long long* prev = q - 8;
+        sum[0] += (double)(q[0] - prev[4]);  // hand-over: mailbox + barrier
+        sum[1] += (double)(q[1] - q[0]);     // K loop
+        sum[2] += (double)(q[2] - q[1]);     // re-align
+        sum[3] += (double)(q[3] - q[2]);     // epilogue until its last instruction is issued
+        sum[4] += (double)(q[4] - q[3]);     // memory counter drains
+        cyc += (double)(q[6] - q[5]);        // shader cycles of the K loop
+        ++cnt;
+      }
+    if (cnt) printf("stamps (us, mean over %ld tiles): handover %.2f  kloop %.2f  realign %.2f  epilogue %.2f  drain %.2f  | K loop %.0f cycles at %.2f GHz | kernel span %.1f us\n", cnt,
+                    sum[0] / cnt * 0.01, sum[1] / cnt * 0.01, sum[2] / cnt * 0.01, sum[3] / cnt * 0.01, sum[4] / cnt * 0.01, cyc / cnt, cyc / (sum[1] * 10.0), (double)(t_last - t_first) * 0.01);
+  }
+#endif
+  if (PDT_ABLATE == 0 && PDT_LAYOUT != 2 && PDT_EPI == PDT_EPI_PLAIN) {  // spot check against the host: 64 random elements
     // a fresh launch into a zeroed C (after the 55 launches above: the ticket counters must have been re-armed every time)
     CK(hipMemset(C, 0, (size_t)M * N * 2));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
@@ -78,6 +150,6 @@ int main(int argc, char** argv) {
     }
     printf("grid=%d  worst relative error of %d sampled outputs (every tile): %.2e %s\n", grid, nsamp, worst, worst < 2e-2 ? "ok" : "MISMATCH");
   }
-  printf("layout=%d phases=%d ablate=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
+  printf("layout=%d phases=%d ablate=%d epi=%d fast=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, (int)g.epi, g.fast_epi, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
   return 0;
 }

@@ -69,6 +69,9 @@ typedef struct PdtGemm {
   // EPI_SLAB_F32 with ONE slab: add the tile to what C holds instead of overwriting it - a weight gradient whose K
   // is not split accumulates straight into the gradient arena, with no slab buffer and no reduction kernel
   int slab_accumulate;
+  // (set by the launcher) the 256x256 ping-pong kernel may use its straight-line epilogue for tiles that lie completely
+  // inside the output: the epilogue kind has one and every tensor it touches is addressable with 31-bit byte offsets
+  int fast_epi;
 } PdtGemm;
 
 // tile: 0 = 128x128 (4 waves, double-buffered, 2 workgroups per CU), 1 = 256x256 (8 waves, one barrier per K-tile),
@@ -88,6 +91,10 @@ int pdt_gemm_max_splits(void);
 // granularity instead of at the end of a whole GEMM).
 int pdt_gemm_persist_mode(void);
 void pdt_gemm_set_persist_mode(int mode);
+// Straight-line epilogue of the ping-pong kernel for full tiles (csrc/kernels/gemm8_epilogue.hpp): 1 on (default; the
+// PDT_GEMM_FAST_EPI environment variable), 0 = the general epilogue everywhere (A/B switch)
+int pdt_gemm_fast_epi_mode(void);
+void pdt_gemm_set_fast_epi_mode(int on);
 // K split of forward / dgrad GEMMs with few output tiles (see pdt_gemm_splits): 1 on (default), 0 off
 void pdt_gemm_set_split_mode(int on);
 int pdt_gemm_split_mode(void);

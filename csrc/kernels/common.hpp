@@ -46,6 +46,14 @@ __device__ __forceinline__ void pdt_lds_dma16(int4v rsrc, const void* lds_dst, u
                :: "s"(lds_addr), "v"(voff), "s"(rsrc));
 }
 
+// One dword per lane through the same path (buffer_load_dword ... lds: lane l lands at lds_dst + 4*l): used to pull the
+// cache lines the lanes point at into the XCD's L2 ahead of the real transfer; the 256 B it writes are junk.
+__device__ __forceinline__ void pdt_lds_dma4(int4v rsrc, const void* lds_dst, uint32_t voff) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)PDT_LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc));
+}
+
 // dtype codes shared with the host side
 enum : int { DT_F16 = 0, DT_BF16 = 1 };
 

@@ -14,6 +14,12 @@
 #pragma once
 #include "common.hpp"
 
+// PDT_EPI_ABLATE (bench/micro/gemm8_ablate.hip only; results are wrong by construction): bit 0 = no global stores,
+// bit 1 = no side-input loads, bit 2 = no LDS transpose of the accumulators
+#ifndef PDT_EPI_ABLATE
+#define PDT_EPI_ABLATE 0
+#endif
+
 namespace pdt {
 
 enum GemmEpilogue : int {
@@ -43,7 +49,7 @@ struct GemmKernel {
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
   static_assert(STAGES == 2 || STAGES == 4, "ring depth");
   static constexpr int A_PASSES = A_BYTES / (NT * 16), B_PASSES = B_BYTES / (NT * 16);
-  static_assert(WTN == 64, "staged epilogue assumes 64 output columns per wave");
+  // (the staged epilogue assumes 64 output columns per wave: other wave shapes only write fp32 slabs)
   static_assert(A_BYTES % (NT * 16) == 0 && B_BYTES % (NT * 16) == 0, "tile/threads mismatch");
   static_assert(WAVES_M * WAVES_N * 32 * 256 <= LDS_BYTES, "epilogue staging does not fit");
 
@@ -109,6 +115,14 @@ struct GemmKernel {
       const uint32_t records = KS ? (uint32_t)(((size_t)(klen - 1) * ld + BX) * 2) : (uint32_t)(((size_t)(BX - 1) * ld + klen) * 2);
       rsrc = pdt_make_rsrc(base, records);
     }
+    // L2 prefetch: one dword per lane from 64 different 128-B lines of K-tile `kt` of this window - K-contiguous: rows
+    // part*64 + lane; K-strided: the 64 k-rows, line `part` (columns part*64 ..) of each.  The 256 B land at `junk`.
+    // Offsets past the window are dropped by the buffer unit (no access).
+    __device__ __forceinline__ void touch(char* junk, int kt, int part, int ld, int lane) {
+      const uint32_t o = KS ? (uint32_t)lane * (uint32_t)ld * 2u + (uint32_t)part * 128u + (uint32_t)kt * kstep
+                            : (uint32_t)(part * 64 + lane) * (uint32_t)ld * 2u + (uint32_t)kt * kstep;
+      pdt_lds_dma4(rsrc, junk, o);
+    }
     // issue this operand's LDS-DMA loads for K-tile `kt` into `dst` (wave-uniform LDS base of the image)
     __device__ __forceinline__ void issue(char* dst, int kt, int klen, int wave) {
 #pragma unroll
@@ -160,7 +174,8 @@ struct GemmKernel {
       // exp / rcp in the data-gradient epilogue).  Not read again before backward: keep it out of the caches.
       float d[8];
       gelu8(v, d);
-      __builtin_nontemporal_store(pack8<T>(d), reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n));
+      if (PDT_EPI_ABLATE & 1) { const short8 pd = pack8<T>(d); asm volatile("" :: "v"(pd)); }
+      else __builtin_nontemporal_store(pack8<T>(d), reinterpret_cast<short8*>((T*)g.aux + (size_t)m * g.ldaux + n));
     } else if (epi == EPI_BIAS_TANH) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = tanhf(v[i]);
@@ -182,7 +197,8 @@ struct GemmKernel {
       for (int i = 0; i < 8; ++i) v[i] += r[i];
     }
     const short8 packed = pack8<T>(v);
-    *reinterpret_cast<short8*>((T*)g.C + (size_t)m * g.ldc + n) = packed;
+    if (PDT_EPI_ABLATE & 1) asm volatile("" :: "v"(packed));
+    else *reinterpret_cast<short8*>((T*)g.C + (size_t)m * g.ldc + n) = packed;
     if (g.colsum) unpack8<T>(packed, v);  // column sums are taken over exactly what was stored
   }
 
@@ -243,7 +259,7 @@ struct GemmKernel {
       for (int it = 0; it < 4; ++it) {
         const int m = mbase(ip) + it * 8 + rsub;
         dst[it] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (has_ext && n_ok && m < g.M) dst[it] = *reinterpret_cast<const short8*>(ext + (size_t)m * ldx + n);
+        if (!(PDT_EPI_ABLATE & 2) && has_ext && n_ok && m < g.M) dst[it] = *reinterpret_cast<const short8*>(ext + (size_t)m * ldx + n);
       }
     };
     fetch(0, xin[0]);
@@ -264,6 +280,7 @@ struct GemmKernel {
     for (int ip = 0; ip < NIP; ++ip) {
       if (ip + 1 < NIP) fetch(ip + 1, xin[(ip + 1) & 1]);
       const uint32_t drow_off = drow_offs[ip];
+      if (!(PDT_EPI_ABLATE & 4)) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = h * 16 + lm;
@@ -273,12 +290,13 @@ struct GemmKernel {
           *reinterpret_cast<float4v*>(stg + row * 256 + chunk * 16) = acc[ip * 2 + h][j];
         }
       }
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + rsub;
         const int key = row & 15;
-        const float4v lo = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
-        const float4v hi = *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
+        const float4v lo = (PDT_EPI_ABLATE & 4) ? acc[ip * 2 + (it >> 1)][(it & 1) * 2] : *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc) ^ key) << 4));
+        const float4v hi = (PDT_EPI_ABLATE & 4) ? acc[ip * 2 + (it >> 1)][(it & 1) * 2 + 1] : *reinterpret_cast<const float4v*>(stg + row * 256 + (((2 * jc + 1) ^ key) << 4));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const int m = mbase(ip) + row;
         if (m < g.M && n_ok) {
@@ -438,9 +456,9 @@ struct GemmKernel {
       }
       return;
     }
-    static_assert(FN == 4 && FM % 2 == 0 && WAVES_M == 2, "staged epilogue shape (2 partial column-sum rows per tile row)");
-    staged_epilogue<FM / 2>(g, acc, smem + wave * (32 * 256), n0 + wn * WTN + (lane & 7) * 8,
-                            [&](int ip) { return m0 + wm * WTM + ip * 32; }, tm * WAVES_M + wm, lane);
+    if constexpr (FN == 4 && FM % 2 == 0 && WAVES_M == 2)  // (2 partial column-sum rows per tile row)
+      staged_epilogue<FM / 2>(g, acc, smem + wave * (32 * 256), n0 + wn * WTN + (lane & 7) * 8,
+                              [&](int ip) { return m0 + wm * WTM + ip * 32; }, tm * WAVES_M + wm, lane);
   }
 };
 

@@ -21,8 +21,11 @@
 // offset - the buffer unit writes zeros - so the wait count is the same in every iteration.
 #pragma once
 #include "gemm.hpp"
+#include "gemm8_epilogue.hpp"
 
 // PDT_ABLATE (bench/micro/gemm8_ablate.hip only): compile parts of a phase out to see what bounds the loop
+// (5: the K loop on v_mfma_f32_32x32x16 fed with the same fragment registers, no epilogue - wrong results, the same
+// operand traffic: what the other MFMA shape does to cycles and clock)
 #ifndef PDT_GROUP_M8
 #define PDT_GROUP_M8 8  // tile rows per rasterisation group of this kernel (see tile_coords)
 #endif
@@ -38,6 +41,15 @@
 // per phase, half as many barriers.
 #ifndef PDT_PHASES
 #define PDT_PHASES 2
+#endif
+// PDT_L2_TOUCH = D > 0: wave 0 of every workgroup pulls a share of the operand panels of K-tile t + 2 + D into the
+// XCD's L2 while K-tile t is multiplied (see the K loop); 0 = off
+#ifndef PDT_L2_TOUCH
+#define PDT_L2_TOUCH 0
+#endif
+// PDT_STAMP(id) (bench/micro/gemm8_ablate.hip only): in-kernel time stamps at the tile / K loop / epilogue boundaries
+#ifndef PDT_STAMP
+#define PDT_STAMP(id) do { } while (0)
 #endif
 
 namespace pdt {
@@ -96,9 +108,11 @@ struct Gemm8 {
     LoaderA la0, la1;
     LoaderB lb0, lb1;
     int klen;
+    int qa = 0, qb = 0;  // which quarter of its A / B panel this workgroup prefetches into L2 (PDT_L2_TOUCH)
     {
       int tm, tn, split;
       locate(cur, tm, tn, split);
+      qa = tn & 3; qb = tm & 3;
       const int kb = split * g.k_per_split;
       klen = min(g.K - kb, g.k_per_split);  // (persistent launches: the same for every tile)
       la0.init((const T*)g.A, g.lda, g.M, tm * 256, kb, klen, tid);
@@ -109,6 +123,9 @@ struct Gemm8 {
     const int nkt = (klen + BK - 1) / BK;
 
     float4v acc[8][4];
+    typedef float float16v __attribute__((ext_vector_type(16)));
+    float16v acc32[8];
+    (void)acc32;
 
     // stage(i, tile): issue half tile i (0:A0 1:B0 2:B1 3:A1) of K-tile `tile` into ring buffer tile&1.
     // Tiles at or beyond nkt belong to the next output tile of a persistent workgroup (the loaders have been
@@ -133,12 +150,21 @@ struct Gemm8 {
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 
+    int stamp_seq = 0;
+    (void)stamp_seq;
     for (;;) {
     const bool has_next = nxt >= 0;
+    PDT_STAMP(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    if (PDT_ABLATE == 5) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+    }
     // K-tile 0 has landed (every wave waited for its own share before this barrier)
     __builtin_amdgcn_s_barrier();
     // the second wave group runs one barrier behind the first from here on
@@ -151,6 +177,13 @@ struct Gemm8 {
   do {                                                                                       \
     if (PDT_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                        \
     if (PDT_PRIO == 2) __builtin_amdgcn_s_setprio(0);                                        \
+    if (PDT_ABLATE == 5) {                                                                   \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                       \
+      _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                       \
+        acc32[((MH)*2 + (NH)) * 2 + b_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(            \
+            __builtin_bit_cast(half8, FB[b_][s_ & 1]), __builtin_bit_cast(half8, fa[b_ * 2 + (s_ >> 1)][s_ & 1]), \
+            acc32[((MH)*2 + (NH)) * 2 + b_], 0, 0, 0);                                       \
+    } else                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                         \
@@ -280,6 +313,18 @@ struct Gemm8 {
       PDT_STAGE(0, t + 2);
       PDT_STAGE(1, t + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // L2 prefetch, issued behind the wait so that it has a whole K-tile to return before the next one: the four
+      // workgroups of an XCD that share an A panel (eight: a B panel) ask for the same lines at the same time, so every
+      // one of them sees the latency of the miss; a quarter of each panel touched D K-tiles early by each of them turns
+      // the real transfers into L2 hits.  The junk dword per lane goes where this wave's next real transfer (B1 of
+      // K-tile t+2, issued in the next phase, returned in order behind it) writes anyway.
+      if (PDT_L2_TOUCH > 0 && wave == 0 && t + 2 + PDT_L2_TOUCH < nkt) {
+        char* junk = smem + (t & 1) * BUF_BYTES + OFF_B1;
+        if (qa & 2) la1.touch(junk, t + 2 + PDT_L2_TOUCH, qa & 1, g.lda, lane);
+        else la0.touch(junk, t + 2 + PDT_L2_TOUCH, qa & 1, g.lda, lane);
+        if (qb & 2) lb1.touch(junk, t + 2 + PDT_L2_TOUCH, qb & 1, g.ldb, lane);
+        else lb0.touch(junk, t + 2 + PDT_L2_TOUCH, qb & 1, g.ldb, lane);
+      }
       PDT_SYNC_LOADS2();
       PDT_MFMA_QUADRANT(1, fb1, 1);
       PDT_MFMA_QUADRANT(1, fb0, 0);
@@ -290,8 +335,10 @@ struct Gemm8 {
     // re-align the two wave groups: every wave has retired its last fragment reads.  The DMA still in flight
     // (the next tile's first K-tiles, or zero fill) targets buffer 0 and the A0/B0 slots of buffer 1; the epilogue
     // stages through the B1/A1 slots of buffer 1 and the 32 KiB behind the ring, so nothing has to drain here.
+    PDT_STAMP(1);
     if (wr == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
+    PDT_STAMP(2);
 
     // ------------------------------------------------------------------ epilogue
     // The epilogue re-reads its (many) arguments from the kernel-argument segment for every tile, through a
@@ -312,7 +359,10 @@ struct Gemm8 {
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int lm = lane_e & 15, lg = lane_e >> 4;
-    if (PDT_ABLATE == 4) {  // no epilogue: keep the accumulators alive, store nothing
+    if (PDT_ABLATE == 5) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(acc32[i]));
+    } else if (PDT_ABLATE == 4) {  // no epilogue: keep the accumulators alive, store nothing
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -336,12 +386,18 @@ struct Gemm8 {
       // m-half ip>>1, rows (ip&1)*32.. of the wave's 64
       char* stg = wave < 4 ? smem + LDS_RING_BYTES + wave * (32 * 256)
                            : smem + BUF_BYTES + OFF_B1 + (wave - 4) * (32 * 256);
-      Base::template staged_epilogue<4>(ge, acc, stg, n0 + ((lane_e & 7) >> 2) * 128 + wc * 32 + (lane_e & 3) * 8,
-                                        [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, tm * 2 + wr, lane_e);
+      if (ge.fast_epi != 0 && m0 + 256 <= ge.M && n0 + 256 <= ge.N)
+        FastEpilogue8<T, AKS, BKS>::run(ge, acc, stg, m0 + wr * 64, n0 + wc * 32, tm * 2 + wr, lane_e);
+      else
+        Base::template staged_epilogue<4>(ge, acc, stg, n0 + ((lane_e & 7) >> 2) * 128 + wc * 32 + (lane_e & 3) * 8,
+                                          [&](int ip) { return m0 + (ip >> 1) * 128 + wr * 64 + (ip & 1) * 32; }, tm * 2 + wr, lane_e);
     }
     // the loads staged for the next tile (K-tile 0 and half of K-tile 1) were issued before the epilogue's own
     // memory operations: an empty counter means they have landed (and, at the end, that no zero fill is in flight)
+    PDT_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PDT_STAMP(4);
+    ++stamp_seq;
     if (!has_next) break;
     // hand the drawn tile id (or -1: the XCD's tiles are all taken) to the other waves through the first word of
     // wave 0's staging area; they read it behind the barrier at the top of the next tile
@@ -354,6 +410,11 @@ struct Gemm8 {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     cur = nxt;
+    if (PDT_L2_TOUCH > 0) {
+      int ntm_, ntn_, ns_;
+      locate(cur, ntm_, ntn_, ns_);
+      qa = ntn_ & 3; qb = ntm_ & 3;
+    }
     __builtin_amdgcn_s_barrier();
     nxt = __builtin_amdgcn_readfirstlane(*mailbox);
     {

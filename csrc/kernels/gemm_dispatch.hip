@@ -84,6 +84,16 @@ extern "C" int pdt_gemm_persist_mode(void) {
 }
 extern "C" void pdt_gemm_set_persist_mode(int mode) { g_persist_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
+static int g_fast_epi = -1;  // -1: not decided yet (read PDT_GEMM_FAST_EPI at first use)
+extern "C" int pdt_gemm_fast_epi_mode(void) {
+  if (g_fast_epi < 0) {
+    const char* e = getenv("PDT_GEMM_FAST_EPI");
+    g_fast_epi = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_fast_epi;
+}
+extern "C" void pdt_gemm_set_fast_epi_mode(int on) { g_fast_epi = on ? 1 : 0; }
+
 // number of fp32 slabs a weight-gradient GEMM of this shape will write (what the caller must allocate)
 // K split of forward / dgrad GEMMs with few output tiles (pdt_gemm_splits): on by default - a lone short micro-batch
 // is latency-bound and a split K shortens every GEMM of the dependent chain (BERT-large, batch 8: 809 vs 745

@@ -6,6 +6,7 @@
 #include "gemm8.hpp"
 
 extern "C" int pdt_gemm_persist_mode(void);  // gemm_dispatch.hip
+extern "C" int pdt_gemm_fast_epi_mode(void);
 
 namespace pdt {
 
@@ -138,6 +139,16 @@ static int launch_pingpong(PdtGemm& g, hipStream_t stream) {
   if (g.epi != PDT_EPI_SLAB_F32) {
     g.splits = 1;
     g.k_per_split = ((g.K + 63) / 64) * 64;
+  }
+  // straight-line epilogue for full tiles (gemm8_epilogue.hpp): byte offsets into C / res / aux are 32-bit there
+  {
+    const int e = g.epi;
+    auto fits = [&](int ld) { return (int64_t)g.M * ld * 2 < 0x7FFFFFFFll; };
+    const bool kind = e == PDT_EPI_PLAIN || e == PDT_EPI_BIAS || e == PDT_EPI_BIAS_GELU || e == PDT_EPI_BIAS_DROP_RES ||
+                      e == PDT_EPI_MUL_DGELU || e == PDT_EPI_ADD_RES;
+    const bool side = (e != PDT_EPI_BIAS_DROP_RES && e != PDT_EPI_ADD_RES) || (g.res != nullptr && fits(g.ldr) && g.ldr >= g.N);
+    const bool aux = (e != PDT_EPI_BIAS_GELU && e != PDT_EPI_MUL_DGELU) || (g.aux != nullptr && fits(g.ldaux) && g.ldaux >= g.N);
+    g.fast_epi = (pdt_gemm_fast_epi_mode() != 0 && kind && side && aux && fits(g.ldc) && g.ldc >= g.N) ? 1 : 0;
   }
   int grid = g.tiles_m * g.tiles_n * g.splits;
   // persistent launch (one workgroup per CU walks several output tiles, see Gemm8::run): needs every tile full, an
