@@ -25,6 +25,13 @@ __device__ unsigned long long* pdt_stamp_buf;
   q_[(id)] = wall_clock64(); if ((id) < 2) q_[5 + (id)] = __builtin_readcyclecounter(); } } while (0)
 #endif
 #include "../../csrc/kernels/gemm8.hpp"
+// -DPDT_KERNEL4=1: time the four-wave kernel (csrc/kernels/gemm4.hpp) instead of the ping-pong kernel
+#ifndef PDT_KERNEL4
+#define PDT_KERNEL4 0
+#endif
+#if PDT_KERNEL4
+#include "gemm4.hpp"
+#endif
 #ifndef PDT_EPI
 #define PDT_EPI PDT_EPI_PLAIN
 #endif
@@ -70,8 +77,14 @@ int main(int argc, char** argv) {
   g.fast_epi = (argc > 5 ? atoi(argv[5]) : 1) != 0 && (long long)M * N * 2 < 0x7FFFFFFFll;
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256; g.splits = splits;
   g.k_per_split = ((K / 64 + splits - 1) / splits) * 64;
+#if PDT_KERNEL4
+  auto kern = pdt::gemm4_kernel<_Float16, AKS, BKS>;
+  using KK = pdt::Gemm4<_Float16, AKS, BKS>;
+#else
   auto kern = pdt::gemm8_kernel<_Float16, AKS, BKS>;
   using KK = pdt::Gemm8<_Float16, AKS, BKS>;
+#endif
+  const int threads = KK::NT;
   CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KK::LDS_BYTES));
   const int total = g.tiles_m * g.tiles_n * splits;
   // argv[4]: workgroups of a persistent launch (0 = one workgroup per tile); needs full tiles and an even K-tile count
@@ -89,12 +102,12 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 #endif
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), KK::LDS_BYTES, 0, g);
   CK(hipDeviceSynchronize());
   float best = 1e9;
   for (int r = 0; r < 5; ++r) {
     CK(hipEventRecord(ev0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), KK::LDS_BYTES, 0, g);
     CK(hipEventRecord(ev1)); CK(hipEventSynchronize(ev1));
     float ms; CK(hipEventElapsedTime(&ms, ev0, ev1));
     if (ms / 10 < best) best = ms / 10;
@@ -103,7 +116,7 @@ int main(int argc, char** argv) {
   {
     const size_t n = stamp_n;
     CK(hipMemset(sb, 0, n * 8));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), KK::LDS_BYTES, 0, g);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hsb(n);
     CK(hipMemcpy(hsb.data(), sb, n * 8, hipMemcpyDeviceToHost));
@@ -131,7 +144,7 @@ int main(int argc, char** argv) {
   if (PDT_ABLATE == 0 && PDT_LAYOUT != 2 && PDT_EPI == PDT_EPI_PLAIN) {  // spot check against the host: 64 random elements
     // a fresh launch into a zeroed C (after the 55 launches above: the ticket counters must have been re-armed every time)
     CK(hipMemset(C, 0, (size_t)M * N * 2));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), KK::LDS_BYTES, 0, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), KK::LDS_BYTES, 0, g);
     CK(hipDeviceSynchronize());
     std::vector<_Float16> hc((size_t)M * N);
     CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
@@ -150,6 +163,6 @@ int main(int argc, char** argv) {
     }
     printf("grid=%d  worst relative error of %d sampled outputs (every tile): %.2e %s\n", grid, nsamp, worst, worst < 2e-2 ? "ok" : "MISMATCH");
   }
-  printf("layout=%d phases=%d ablate=%d epi=%d fast=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, (int)g.epi, g.fast_epi, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
+  printf("kernel=%s layout=%d phases=%d ablate=%d epi=%d fast=%d M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s(nominal)\n", PDT_KERNEL4 ? "4wave" : "pingpong", PDT_LAYOUT, PDT_PHASES, PDT_ABLATE, (int)g.epi, g.fast_epi, M, N, K, best * 1e3, 2.0 * M * N * K / (best * 1e-3) / 1e12);
   return 0;
 }

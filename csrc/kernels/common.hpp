@@ -46,6 +46,15 @@ __device__ __forceinline__ void pdt_lds_dma16(int4v rsrc, const void* lds_dst, u
                :: "s"(lds_addr), "v"(voff), "s"(rsrc));
 }
 
+// The same with a scalar byte offset added to every lane's (the K-tile's position: the per-lane offsets of a tile
+// window then never change and no vector instruction is spent per transfer).  The scalar offset may not be covered by
+// the descriptor's range check: only pass offsets that keep in-range lanes inside the window.
+__device__ __forceinline__ void pdt_lds_dma16_s(int4v rsrc, const void* lds_dst, uint32_t voff, uint32_t soff) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)PDT_LDS_PTR(lds_dst));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff));
+}
+
 // One dword per lane through the same path (buffer_load_dword ... lds: lane l lands at lds_dst + 4*l): used to pull the
 // cache lines the lanes point at into the XCD's L2 ahead of the real transfer; the 256 B it writes are junk.
 __device__ __forceinline__ void pdt_lds_dma4(int4v rsrc, const void* lds_dst, uint32_t voff) {

@@ -73,7 +73,8 @@ struct Gemm8 {
     return AKS ? Base::template frag_ks<128>(img, x0, ks, lane) : Base::frag_kc(img, x0, ks, lane);
   }
   static __device__ __forceinline__ short8 fragB(const char* img, int x0, int ks, int lane) {
-    if (PDT_ABLATE == 2) { short8 r; for (int i = 0; i < 8; ++i) r[i] = (short)(x0 * 3 + ks + lane); return r; }
+    // (6: no B fragment reads - a third of the LDS read bytes, what a 128 x 128 wave tile would save)
+    if (PDT_ABLATE == 2 || PDT_ABLATE == 6) { short8 r; for (int i = 0; i < 8; ++i) r[i] = (short)(x0 * 3 + ks + lane); return r; }
     return BKS ? Base::template frag_ks<128>(img, x0, ks, lane) : Base::frag_kc(img, x0, ks, lane);
   }
 
@@ -298,6 +299,16 @@ struct Gemm8 {
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fb1[ni][ks] = fragB(buf + OFF_B1, bcol + ni * 16, ks, lane);
+      if (PDT_ABLATE == 7) {  // a third MORE LDS read bytes (8 extra fragment reads per K-tile, results discarded)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const short8 x0_ = fragB(buf + OFF_B0, ((bcol + 64) & 127) + ni * 16, ks, lane);
+            const short8 x1_ = fragB(buf + OFF_B1, ((bcol + 64) & 127) + ni * 16, ks, lane);
+            asm volatile("" :: "v"(x0_), "v"(x1_));
+          }
+      }
       PDT_RETARGET_B1A1();
       PDT_STAGE(2, t + 1);
       PDT_STAGE(3, t + 1);
