@@ -46,6 +46,7 @@ from pytorch_distributed_training_amd.optim import AdamW, get_linear_schedule_wi
 # samples/s of the reference's software stack (transformers + torch AMP, SDPA attention) on one MI355X: bert-large-cased,
 # seq 128, batch 1024, fp16 - bench/eager_baseline.py; 2014 / 2018 / 1993 in three table runs (profiles/perf_table_*.jsonl)
 REFERENCE_STACK_1GPU = 2014.0
+POOL_BATCHES = 16  # distinct synthetic batches a run cycles through
 
 
 def main() -> None:
@@ -74,6 +75,10 @@ def main() -> None:
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="single GPU only: run the data-parallel machinery anyway (1-rank RCCL group, every bucket "
                          "all-reduce really issued on RCCL's stream) to see what the gradient path costs besides the wire")
+    ap.add_argument("--gemm-persist", type=int, default=None, choices=[0, 1, 2],
+                    help="persistent launches of the large GEMMs (256 workgroups walk the output tiles): 0 never, 1 from 4 "
+                         "tiles per workgroup, 2 from 2.  Default: 1 on one GPU, 0 in multi-rank runs, where one workgroup "
+                         "per tile lets the communication kernels of other streams onto the CUs at tile granularity")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()
@@ -85,6 +90,8 @@ def main() -> None:
         args.batch = max(1, 131072 // args.seq_len)
     if args.comm_algo:
         os.environ["PDT_COMM_ALGO"] = args.comm_algo
+    if args.gemm_persist is not None:
+        os.environ["PDT_GEMM_PERSIST"] = str(args.gemm_persist)  # (read by the extension and honoured by Engine)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(_self_launch(args.gpus))
@@ -99,7 +106,9 @@ def main() -> None:
             raise SystemExit("--rehearse-dp is a single-GPU rehearsal")
         os.environ["PDT_FORCE_COLLECTIVES"] = "1"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        from pytorch_distributed_training_amd.launch import find_free_port
+
+        os.environ.setdefault("MASTER_PORT", str(find_free_port()))
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm, comm_backend=args.comm)
@@ -119,8 +128,10 @@ def main() -> None:
     model.train()
     micro = args.batch // args.accum
     vocab = eng.unwrap_model(model).config.vocab_size
+    # a pool of fixed synthetic batches, cycled: the timed steps read no new data, so the loss reported at the end is
+    # the loss of a batch the model has seen before (a long run memorises its pool) - a liveness signal, not convergence
     pool = [fixed_batch(micro, args.seq_len, vocab, eng.device, seed=1000 * eng.process_index + i,
-                        first_id=eng.process_index * args.batch + (i % args.accum) * micro) for i in range(4)]
+                        first_id=eng.process_index * args.batch + (i % args.accum) * micro) for i in range(POOL_BATCHES)]
 
     if os.environ.get("PDT_BENCH_NO_SAMPLE_IDS"):  # A/B aid: rank-keyed dropout streams instead of sample-keyed ones
         for b in pool:
@@ -189,7 +200,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
-            "final_loss": float(loss.item()) * args.accum,
+            "last_step_loss": float(loss.item()) * args.accum,
+            "loss_note": f"batches cycle through a pool of {POOL_BATCHES} fixed synthetic batches: not a convergence signal",
             "tokens_per_s": round(value * args.seq_len, 1),
             # model FLOPs (6 x linear-layer parameters + attention products, forward + backward) actually delivered per GPU
             "model_tflops_per_gpu": round(value / world * _flops_per_sample(eng.unwrap_model(model).config, args.seq_len) / 1e12, 1),
@@ -224,6 +236,16 @@ def _self_launch(gpus: int) -> int:
     import subprocess
 
     from pytorch_distributed_training_amd.launch import find_free_port
+
+    # Under a profiler that preloads itself into this process (rocprofv3 does, and with counter collection it starts the
+    # GPU runtime before main() runs) this process HAS touched the GPU, and the launcher it would start re-executes
+    # Python: profile multi-rank runs by putting the profiler in front of the rank processes instead.
+    preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("ROCPROFILER_LIBRARY", "")
+    if "rocprof" in preload.lower() or "ROCPROFILER_SDK_TOOL" in "".join(os.environ.keys()):
+        print("bench.py --gpus N > 1 does not start its own ranks under a profiler: run\n  python -m torch.distributed.run "
+              "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...\nand put the profiler "
+              "inside (e.g. profile one rank), or profile a single-GPU run.", file=sys.stderr)
+        return 2
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(find_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -277,7 +299,7 @@ def bench_pipeline(args, world: int, comm) -> None:
     replica_batch = 2 * args.batch
     # both stage ranks of a replica read the same batches (only hidden states cross the link)
     pool = [fixed_batch(replica_batch, args.seq_len, model_cfg.vocab_size, eng.device, seed=1000 * mesh.replica + i,
-                        first_id=mesh.replica * replica_batch) for i in range(4)]
+                        first_id=mesh.replica * replica_batch) for i in range(POOL_BATCHES)]
     loss = None
 
     def step(i: int):
@@ -316,7 +338,9 @@ def bench_pipeline(args, world: int, comm) -> None:
             "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic MRPC-shaped token batches (random-init weights)",
-            "final_loss": box[0], "tokens_per_s": round(value * args.seq_len, 1),
+            "last_step_loss": box[0],
+            "loss_note": f"batches cycle through a pool of {POOL_BATCHES} fixed synthetic batches: not a convergence signal",
+            "tokens_per_s": round(value * args.seq_len, 1),
             "model_tflops_per_gpu": round(value / world * _flops_per_sample(model_cfg, args.seq_len) / 1e12, 1),
             "comm_exposed_ms_per_step": round(exposed, 3) if exposed is not None else None,
             "rccl_ranks": stage.rccl_ranks() if hasattr(stage, "rccl_ranks") else 0,

@@ -175,6 +175,11 @@ void RcclComm::check_finite_async(const at::Tensor& t, const at::Tensor& scale_s
   TORCH_CHECK(e == 0, "grad_check launch failed: ", e);
 }
 
+void RcclComm::adamw_async(int dtype, const PdtAdamW& args) {
+  const int e = pdt_adamw_step(dtype, &args, stream_);
+  TORCH_CHECK(e == 0, "adamw launch on the communication stream failed: ", e);
+}
+
 void RcclComm::p2p_async(const std::vector<int64_t>& kinds, const std::vector<at::Tensor>& tensors,
                          const std::vector<int64_t>& peers) {
   TORCH_CHECK(kinds.size() == tensors.size() && kinds.size() == peers.size(), "p2p: list lengths differ");

@@ -13,6 +13,7 @@
 // `init_process_group` (/root/reference/test_data_parallelism.py:55, /root/reference/test_model_parallelism.py:166-171).
 #pragma once
 #include <torch/extension.h>
+#include "../kernels/api.h"
 
 #include <memory>
 #include <string>
@@ -50,6 +51,9 @@ class RcclComm {
   // enqueue the non-finite check of fp32 `t` on the communication stream: scale_state[2] = 1 if any element is inf / NaN
   // (the loss scaler's overflow flag; run right behind a bucket's all-reduce it overlaps backward like the all-reduce)
   void check_finite_async(const at::Tensor& t, const at::Tensor& scale_state);
+  // enqueue the fused AdamW update of one bucket on the communication stream, right behind its all-reduce: runs of
+  // precisions without a global skip decision (bf16, fp32) update a bucket while backward is still producing the next
+  void adamw_async(int dtype, const PdtAdamW& args);
   // a group of sends / receives that must progress together: kinds[i] 0 = send, 1 = recv
   void p2p_async(const std::vector<int64_t>& kinds, const std::vector<at::Tensor>& tensors, const std::vector<int64_t>& peers);
 

@@ -96,6 +96,35 @@ class GradBucketReducer {
     launch_ready_prefix();
   }
 
+  // Fused AdamW per bucket, on the communication stream right behind the bucket's collective (own communicator, fp32
+  // wire).  For precisions without a global skip decision only (bf16 / fp32: the caller decides); a bucket that is
+  // reduced as a left-over at the end of backward (nobody completed it: its gradient slice may hold unwritten
+  // segments the optimizer has yet to zero) is left to the optimizer - optimizer_applied() says which.
+  void set_optimizer(Tensor p, Tensor m, Tensor v, c10::optional<Tensor> p16, Tensor lr, Tensor step, Tensor scale_state,
+                     double beta1, double beta2, double eps, double weight_decay, bool correct_bias) {
+    TORCH_CHECK(p.numel() == arena_.numel() && m.numel() == arena_.numel() && v.numel() == arena_.numel(),
+                "optimizer state must cover the gradient arena");
+    TORCH_CHECK(p.scalar_type() == at::kFloat && m.scalar_type() == at::kFloat && v.scalar_type() == at::kFloat, "fp32 state expected");
+    TORCH_CHECK(step.scalar_type() == at::kInt && scale_state.scalar_type() == at::kFloat && scale_state.numel() >= 4 &&
+                lr.scalar_type() == at::kFloat, "lr / step / scale_state: device scalars of the fused optimizer");
+    opt_p_ = std::move(p); opt_m_ = std::move(m); opt_v_ = std::move(v); opt_lr_ = std::move(lr); opt_step_ = std::move(step);
+    opt_state_ = std::move(scale_state);
+    opt_dtype_ = PDT_F16;
+    if (p16.has_value()) {
+      TORCH_CHECK(p16->numel() == arena_.numel(), "16-bit copy must cover the arena");
+      opt_p16_ = *p16;
+      opt_dtype_ = p16->scalar_type() == at::kBFloat16 ? PDT_BF16 : PDT_F16;
+    }
+    opt_args_ = PdtAdamW{};
+    opt_args_.beta1 = (float)beta1; opt_args_.beta2 = (float)beta2; opt_args_.eps = (float)eps;
+    opt_args_.weight_decay = (float)weight_decay; opt_args_.correct_bias = correct_bias ? 1 : 0;
+    opt_set_ = true;
+  }
+  void clear_optimizer() { opt_set_ = false; }
+  bool applies_optimizer() const { return rccl_ && opt_set_ && !comm_dtype_.has_value() && !host_staged_ && (world_ > 1 || force_); }
+  // per bucket: did the last finished backward pass update it on the communication stream?
+  std::vector<bool> optimizer_applied() const { return applied_; }
+
   // End of backward: buckets nobody marked (parameters that took no part in this graph - their arena slice
   // is still zero) are reduced too, in index order, so every rank issues the same sequence of collectives;
   // then the compute stream is made to wait for all of them.
@@ -103,7 +132,7 @@ class GradBucketReducer {
     if (!active_) return;
     active_ = false;
     if (!sync_) return;
-    for (int b = next_; b < nb_; ++b) launch(b);
+    for (int b = next_; b < nb_; ++b) launch(b, /*leftover=*/true);
     next_ = nb_;
     const auto t0 = std::chrono::steady_clock::now();
     if (rccl_ && launched_any_) rccl_->join();  // the compute stream waits for every bucket; the host does not
@@ -181,13 +210,14 @@ class GradBucketReducer {
     works_.assign(nb_, nullptr);
     staged_.assign(nb_, Tensor());
     order_.clear();
+    applied_.assign(nb_, false);
     next_ = 0;
     launched_any_ = false;
   }
   void launch_ready_prefix() {
     while (next_ < nb_ && ready_[next_] >= expected_[next_]) launch(next_++);
   }
-  void launch(int b) {
+  void launch(int b, bool leftover = false) {
     order_.push_back(b);
     if (world_ == 1 && !force_) return;  // nothing to exchange; gradients are already the global ones
     Tensor buf = views_[b];
@@ -212,6 +242,17 @@ class GradBucketReducer {
         rccl_->all_reduce_async(buf, average_);
       }
       if (checks_overflow()) rccl_->check_finite_async(views_[b], overflow_state_);
+      if (applies_optimizer() && !leftover) {
+        PdtAdamW a = opt_args_;
+        const int64_t o = bounds_[b];
+        a.p = opt_p_.data_ptr<float>() + o; a.m = opt_m_.data_ptr<float>() + o; a.v = opt_v_.data_ptr<float>() + o;
+        a.g = arena_.data_ptr<float>() + o;
+        a.p16 = opt_p16_.defined() ? (void*)((char*)opt_p16_.data_ptr() + 2 * o) : nullptr;
+        a.n = bounds_[b + 1] - o;
+        a.lr = opt_lr_.data_ptr<float>(); a.step = opt_step_.data_ptr<int32_t>(); a.scale_state = opt_state_.data_ptr<float>();
+        rccl_->adamw_async(opt_dtype_, a);
+        applied_[b] = true;
+      }
       launched_any_ = true;
     } else {
       c10d::AllreduceOptions opts;
@@ -226,6 +267,11 @@ class GradBucketReducer {
   PG pg_;
   std::shared_ptr<pdt::RcclComm> rccl_;
   Tensor arena_, overflow_state_;
+  Tensor opt_p_, opt_m_, opt_v_, opt_p16_, opt_lr_, opt_step_, opt_state_;
+  PdtAdamW opt_args_{};
+  int opt_dtype_ = PDT_F16;
+  bool opt_set_ = false;
+  std::vector<bool> applied_;
   std::vector<int64_t> bounds_, expected_;
   bool average_;
   c10::optional<at::ScalarType> comm_dtype_;
@@ -253,6 +299,10 @@ void bind_reducer(py::module_& m) {
       .def("finish", &GradBucketReducer::finish, py::call_guard<py::gil_scoped_release>())
       .def("broadcast", &GradBucketReducer::broadcast, py::arg("tensor"), py::arg("root") = 0,
            py::arg("chunk_elems") = (int64_t)16 << 20, py::call_guard<py::gil_scoped_release>())
+      .def("set_optimizer", &GradBucketReducer::set_optimizer)
+      .def("clear_optimizer", &GradBucketReducer::clear_optimizer)
+      .def("applies_optimizer", &GradBucketReducer::applies_optimizer)
+      .def("optimizer_applied", &GradBucketReducer::optimizer_applied)
       .def("set_overflow_state", &GradBucketReducer::set_overflow_state)
       .def("checks_overflow", &GradBucketReducer::checks_overflow)
       .def("num_buckets", &GradBucketReducer::num_buckets)

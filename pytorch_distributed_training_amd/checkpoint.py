@@ -157,6 +157,15 @@ def _tag_of(extra: dict) -> str:
     return f"{int(extra.get('global_step', 0)):08d}-{int(extra.get('epoch', 0))}-{int(extra.get('micro_offset', 0))}"
 
 
+def _tag_key(tag: str):
+    """Order of a tag: (optimizer step, epoch, batches consumed) as integers - only the step field is zero-padded, so as
+    strings "…-10-0" would sort before "…-9-57"."""
+    try:
+        return tuple(int(x) for x in tag.split("-"))
+    except ValueError:
+        return (-1,)
+
+
 def _names(suffix: str):
     if not suffix:
         return WEIGHTS, STATE, "latest.json"
@@ -193,7 +202,10 @@ def save_training_state(directory: str, model: nn.Module, optimizer=None, schedu
         state["scheduler"] = scheduler.state_dict()
     rt = getattr(m, "runtime", None)
     if rt is not None:
-        state["rng"] = {"state": rt.rng_state.cpu(), "micro": rt.micro, "window": rt.arena.window}
+        # (rng_state_global: the stream of batches that carry sample ids; a graphed step advances its offset on the
+        # device at every replay, so it is part of the position of the run)
+        state["rng"] = {"state": rt.rng_state.cpu(), "global": rt.rng_state_global.cpu(), "micro": rt.micro,
+                        "window": rt.arena.window}
     state["torch_rng"] = torch.get_rng_state()
     path = os.path.join(sub, sname)
     tmp = path + ".tmp"
@@ -203,7 +215,7 @@ def save_training_state(directory: str, model: nn.Module, optimizer=None, schedu
         "dir": f"checkpoint-{tag}", "weights": wname, "state": sname,
         "extra": {k: v for k, v in extra.items() if isinstance(v, (int, float, str, bool))}})
     # older checkpoints: this writer removes its own files, the directory goes with its last file
-    mine = sorted(t for t in available_tags(directory, suffix) if t != tag)
+    mine = sorted((t for t in available_tags(directory, suffix) if t != tag), key=_tag_key)
     for old in mine[:max(0, len(mine) - (keep - 1))]:
         odir = os.path.join(directory, f"checkpoint-{old}")
         for name in (wname, sname) + (("config.json",) if write_config else ()):
@@ -227,7 +239,7 @@ def available_tags(directory: str, suffix: str = ""):
     for d in os.listdir(directory):
         if d.startswith("checkpoint-") and all(os.path.exists(os.path.join(directory, d, n)) for n in (wname, sname)):
             out.append(d[len("checkpoint-"):])
-    return sorted(out)
+    return sorted(out, key=_tag_key)
 
 
 def latest_tag(directory: Optional[str], suffix: str = "") -> Optional[str]:
@@ -249,13 +261,13 @@ def common_tag(directory: Optional[str], suffix: str, group=None) -> Optional[st
 
     mine = set(available_tags(directory, suffix)) if directory else set()
     newest = latest_tag(directory, suffix)
-    mine = {t for t in mine if newest is not None and t <= newest}  # nothing newer than what was published
+    mine = {t for t in mine if newest is not None and _tag_key(t) <= _tag_key(newest)}  # nothing newer than what was published
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return max(mine) if mine else None
+        return max(mine, key=_tag_key) if mine else None
     every = [None] * dist.get_world_size(group)
-    dist.all_gather_object(every, sorted(mine), group=group)
+    dist.all_gather_object(every, sorted(mine, key=_tag_key), group=group)
     common = set(every[0]).intersection(*map(set, every[1:]))
-    return max(common) if common else None
+    return max(common, key=_tag_key) if common else None
 
 
 def load_training_state(directory: str, model: nn.Module, optimizer=None, scheduler=None, suffix: str = "",
@@ -280,6 +292,8 @@ def load_training_state(directory: str, model: nn.Module, optimizer=None, schedu
     rt = getattr(m, "runtime", None)
     if rt is not None and "rng" in state:
         rt.rng_state.copy_(state["rng"]["state"].to(rt.rng_state.device))
+        if "global" in state["rng"]:
+            rt.rng_state_global.copy_(state["rng"]["global"].to(rt.rng_state_global.device))
         rt.micro = int(state["rng"]["micro"])
         rt.arena.window = int(state["rng"].get("window", rt.arena.window))
     if "torch_rng" in state:

@@ -74,28 +74,40 @@ class TrainConfig:
     save_every: int = 0
     init_from: Optional[str] = None  # directory with HF-layout weights (config.json + safetensors / bin)
 
-    def micro_batch_cap(self, device=None, model_cfg=None) -> int:
+    def micro_batch_cap(self, device=None, model_cfg=None, free_bytes: Optional[int] = None) -> int:
         """Largest micro-batch one GPU runs.  An explicit ``--max-gpu-batch-size N`` wins.  0 (default) sizes it for the
         GPU the process drives: the reference's constant 8 (/root/reference/test_data_parallelism.py:49, chosen for
         16-GB cards) on the CPU and with ``--compat``; on a GPU as many samples as fit a budget of half the free HBM
         and at most 131072 tokens (the shape the kernels are tuned for), counting a sample at the longest length the
         collator can produce and ~34 bytes of saved activations per token, layer and hidden unit (measured: 106 GB
-        for 131072 tokens of BERT-large)."""
+        for 131072 tokens of BERT-large).
+
+        Free memory is a per-rank reading (a co-tenant, several ranks rehearsing on one card), but the micro-batch
+        decides the loaders' batch size, the number of optimizer steps per epoch and the pipeline's message shapes, so
+        the ranks settle on the smallest cap among them (``launch.agree_min``: collective over the world - every rank of
+        a run calls this at the same point of its recipe).  `free_bytes` replaces the device query (tests)."""
         if self.max_gpu_batch_size > 0:
             return self.max_gpu_batch_size
         if self.compat or device is None or getattr(device, "type", "cpu") != "cuda" or model_cfg is None:
             return 8
-        import torch
+        from .launch import agree_min
 
-        free, _total = torch.cuda.mem_get_info(device)
+        if free_bytes is None:
+            import torch
+
+            free_bytes, _total = torch.cuda.mem_get_info(device)
         per_token = 34 * model_cfg.num_hidden_layers * model_cfg.hidden_size
         seq = self.max_length or model_cfg.max_position_embeddings
-        tokens = min(131072, int(0.5 * free) // per_token)
-        return max(8, tokens // max(1, seq))
+        tokens = min(131072, int(0.5 * free_bytes) // per_token)
+        cap = max(8, tokens // max(1, seq))
+        agreed = agree_min(cap, device if hasattr(device, "index") else None)
+        if agreed != cap:
+            print(f"[config] micro-batch cap {cap} on this rank, {agreed} agreed across ranks", flush=True)
+        return agreed
 
-    def accumulation(self, device=None, model_cfg=None):
+    def accumulation(self, device=None, model_cfg=None, free_bytes: Optional[int] = None):
         """The reference's accumulation policy (/root/reference/test_data_parallelism.py:90-93) on `micro_batch_cap`."""
-        cap = self.micro_batch_cap(device, model_cfg)
+        cap = self.micro_batch_cap(device, model_cfg, free_bytes)
         if self.batch_size > cap:
             return self.batch_size // cap, cap
         return 1, self.batch_size

@@ -77,7 +77,8 @@ class EngineOptimizer:
 class Engine:
     def __init__(self, fp16: bool = False, cpu: bool = False, bf16: bool = False, seed: int = 42,
                  comm_dtype: Optional[torch.dtype] = None, min_bucket_mb: float = 4.0, process_group=None,
-                 init_scale: float = 2.0 ** 16, native: Optional[bool] = None, comm_backend: Optional[str] = None):
+                 init_scale: float = 2.0 ** 16, native: Optional[bool] = None, comm_backend: Optional[str] = None,
+                 update_in_backward: bool = True):
         if fp16 and bf16:
             raise ValueError("choose one of fp16 / bf16")
         self.env, self.device = launch.init_distributed(cpu=cpu)
@@ -110,9 +111,14 @@ class Engine:
         self.comm_dtype = comm_dtype
         # gradient all-reduce through c10d's "nccl" backend (default) or the framework's own RcclComm ("rccl")
         self.comm_backend = comm_backend
+        # bf16 / fp32 data-parallel runs on the framework's own communicator: AdamW of a bucket right behind its
+        # all-reduce, inside backward (FusedAdamW.attach_reducer).  False for drivers that touch the reduced gradients
+        # between backward and the optimizer step (gradient clipping) or re-use weights after a bucket completed.
+        self.update_in_backward = update_in_backward
         self.min_bucket_elems = int(min_bucket_mb * (1 << 20) / 4)
         self.scaler = LossScaler(self.device, enabled=fp16 and on_gpu, init_scale=init_scale)
         self._models = []
+        self._fused = []
         self._arena: Optional[ParamArena] = None
 
     # ------------------------------------------------------------------------------------------
@@ -178,6 +184,9 @@ class Engine:
             dps = [m for m in self._models if isinstance(m, DataParallel) and m.arena is self._arena]
             # (the overflow check rides behind the bucket all-reduces when the reducer can do it)
             fused.grads_checked_by_reducer = bool(dps) and all(m.attach_scaler(self.scaler) for m in dps)
+            if self.update_in_backward and len(dps) == 1 and dps[0].auto_arm and not dps[0].manual_finish:
+                fused.attach_reducer(dps[0].reducer)
+            self._fused.append(fused)
             return EngineOptimizer(fused, self)
         return EngineOptimizer(optimizer, self)
 
@@ -208,6 +217,9 @@ class Engine:
         if arena is None:
             params = [p for p in inner.parameters() if p.grad is not None]
             return torch.nn.utils.clip_grad_norm_(params, max_norm)
+        if any(f.arena is arena and f._bucket_reducer is not None for f in self._fused):
+            raise RuntimeError("clip_grad_norm_ after backward has already applied the optimizer bucket by bucket: "
+                               "build the Engine with update_in_backward=False (or PDT_ADAMW_PER_BUCKET=0) to clip")
         sq = torch.linalg.vector_norm(arena.grad).pow(2)
         if group is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
             if sq.is_cuda and dist.get_backend(group) == "gloo":  # single-GPU rehearsal: cross gloo through the host
@@ -251,6 +263,7 @@ class Engine:
             auto_arm, dp.auto_arm = dp.auto_arm, False
         losses = []
         split_k = None
+        queued, rt, streams = {}, None, []  # (state of the overlapped window that the clean-up below has to undo)
         try:
             if not overlap or n < 2:
                 for i, b in enumerate(batches):
@@ -326,9 +339,10 @@ class Engine:
             # rocprofv3 trace (where every launch costs the host more) shows all streams running dry for ~0.45 ms at the
             # end of every backward pass - the host then has to start the next forward AND the next backward from empty
             # queues; unprofiled, the 12 x 8 step measures the same with 1 and 2 (the GPU is the bound there).
-            ahead = max(1, int(os.environ.get("PDT_FWD_AHEAD", "2"))) if threaded else 1
+            # (at most ns - 1: forward(i + ns) shares its stream with backward(i), and two host threads must never
+            # enqueue into one stream at the same time)
+            ahead = min(ns - 1, max(1, int(os.environ.get("PDT_FWD_AHEAD", "2")))) if threaded else 1
             cur, done = forward(0), [None] * n
-            queued = {}
             for j in range(1, min(n, ahead)):  # (forward(i + ahead) is submitted at the top of iteration i)
                 queued[j] = self._fwd_pool.submit(forward, j)
             for i in range(n):
@@ -381,6 +395,24 @@ class Engine:
                 main.wait_event(tail)
             return losses
         finally:
+            # A backward that raised leaves forward passes queued on (or running in) the forward thread: nothing may be
+            # restored while they still run - they would read the switches reset below and set the gradient lane after
+            # this function has returned.  Not-yet-started ones are cancelled, a running one is waited for.
+            for fut in queued.values():
+                if not fut.cancel():
+                    try:
+                        fut.result()
+                    except Exception:  # noqa: BLE001 - the window is being abandoned anyway
+                        pass
+            if rt is not None:
+                rt.lane = 0
+                rt.merge_on_done = False
+                from .ops import native as _native
+
+                _native().set_wgrad_defer(False)
+                for st in streams:  # deferred weight-gradient work of every stream the window used
+                    with torch.cuda.stream(st):
+                        _native().wgrad_join()
             if split_k is not None:
                 _native().set_gemm_split_k(split_k)
             if dp is not None:

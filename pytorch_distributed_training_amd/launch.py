@@ -39,6 +39,25 @@ class DistEnv:
                           MASTER_ADDR=self.master_addr, MASTER_PORT=str(self.master_port))
 
 
+def export_gpu_ipc_env() -> None:
+    """``HSA_ENABLE_IPC_MODE_LEGACY=0`` unless the user set it: dmabuf IPC handles are the only kind the host drivers of
+    MI355X nodes export, and without it RCCL's intra-node transport (and any tensor shared between processes) fails with
+    ``hipIpcGetMemHandle: invalid argument``.  The HIP runtime reads the variable when it initialises, so this runs at
+    package import - before the first HIP call of the process - and again here for scripts that import late."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def agree_min(value: int, device: Optional[torch.device] = None, group=None) -> int:
+    """The smallest `value` over the ranks of `group` (the value itself without a process group): how ranks settle on
+    one number that each of them derived from its own device (free memory, ...).  Collective over the group."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(value)
+    on_gpu = dist.get_backend(group) == "nccl" and device is not None and device.type == "cuda"
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
 def pick_device(cpu: bool, local_rank: int) -> torch.device:
     if cpu or not torch.cuda.is_available():
         return torch.device("cpu")
@@ -66,6 +85,7 @@ def default_backend(device: torch.device, env: DistEnv) -> str:
 def init_distributed(cpu: bool = False, backend: Optional[str] = None, timeout_s: int = 1800,
                      env: Optional[DistEnv] = None) -> Tuple[DistEnv, torch.device]:
     """Join (or create) the default process group described by the environment; idempotent."""
+    export_gpu_ipc_env()
     env = env or DistEnv.from_environ()
     device = pick_device(cpu, env.local_rank)
     if env.world_size > 1 and not dist.is_initialized():

@@ -33,7 +33,8 @@ class Segment:
     params: List[Tuple[str, nn.Parameter]]
     start: int = 0
     end: int = 0
-    bucket: int = -1
+    bucket: int = -1  # first bucket the segment's gradients lie in
+    buckets: Tuple[int, ...] = ()  # every bucket whose completion this segment's completion counts towards
     # gradients of this segment are produced by native kernels that can overwrite (beta=0) on the first
     # backward after zero_grad, so the slice needs no memset
     native_overwrite: bool = False
@@ -90,7 +91,8 @@ def bert_segments(model, prefix: str = "") -> List[Segment]:
 class ParamArena:
     def __init__(self, model: nn.Module, device: torch.device, compute_dtype: Optional[torch.dtype] = None,
                  min_bucket_elems: int = 1 << 20, segments: Optional[List[Segment]] = None,
-                 guard_elems: Optional[int] = None):
+                 guard_elems: Optional[int] = None, max_bucket_elems: Optional[int] = None,
+                 tail_bucket_elems: Optional[int] = None):
         self.model = model
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
@@ -153,6 +155,7 @@ class ParamArena:
             self.bucket_segments.pop()
             for seg in self.segments:
                 seg.bucket = min(seg.bucket, len(self.bucket_bounds) - 2)
+        self._split_large_buckets(max_bucket_elems, tail_bucket_elems)
         self.written = [False] * len(self.segments)  # gradient slice holds this step's values already
         self.grad_alt: Optional[torch.Tensor] = None  # second gradient lane (enable_alt)
         self.written_alt: List[bool] = []
@@ -161,6 +164,43 @@ class ParamArena:
         self.param_segment: Dict[int, int] = {id(p): i for i, s in enumerate(self.segments) for _, p in s.params}
         if self.p16 is not None:
             self.sync_compute_copy()
+
+    def _split_large_buckets(self, max_elems: Optional[int], tail_elems: Optional[int]) -> None:
+        """Cut buckets that are too large for one collective into equal pieces.  A bucket is one segment or a run of
+        small ones, and a segment is as large as its parameters: the embedding tables of BERT-large are 119 MB of fp32
+        gradients, complete only at the very end of backward - as one all-reduce, all of it is exposed behind the
+        backward pass, and nothing (the optimizer on the pieces that have landed, the next piece on another channel)
+        can overlap with it.  `max_elems` (default 64 MB of fp32, ``PDT_MAX_BUCKET_MB``) bounds every bucket,
+        `tail_elems` (default 32 MB, ``PDT_TAIL_BUCKET_MB``) the last one of backward.  Every piece waits for all
+        segments of the bucket it was cut from (a piece does not follow parameter boundaries)."""
+        import os
+
+        if max_elems is None:
+            max_elems = int(float(os.environ.get("PDT_MAX_BUCKET_MB", "64")) * (1 << 20) / 4)
+        if tail_elems is None:
+            tail_elems = int(float(os.environ.get("PDT_TAIL_BUCKET_MB", "32")) * (1 << 20) / 4)
+        unit = 8 * ALIGN  # piece boundaries: aligned like parameters, and a multiple of any rank count up to 8
+        old_bounds, old_expected = self.bucket_bounds, self.bucket_segments
+        nb = len(old_bounds) - 1
+        bounds, expected, parts = [0], [], []
+        for b in range(nb):
+            lo, hi = old_bounds[b], old_bounds[b + 1]
+            cap = min(max_elems, tail_elems) if b == nb - 1 else max_elems
+            k = max(1, -(-(hi - lo) // cap)) if cap > 0 else 1
+            step = -(-((hi - lo) // k) // unit) * unit if k > 1 else hi - lo
+            mine = []
+            for j in range(k):
+                end = hi if j == k - 1 else min(hi, lo + (j + 1) * step)
+                if end <= bounds[-1]:
+                    continue
+                mine.append(len(bounds) - 1)
+                bounds.append(end)
+                expected.append(old_expected[b])
+            parts.append(tuple(mine))
+        self.bucket_bounds, self.bucket_segments = bounds, expected
+        for seg in self.segments:
+            seg.buckets = parts[seg.bucket]
+            seg.bucket = seg.buckets[0]
 
     # ------------------------------------------------------------------------------------------
     _GUARD32, _GUARD16 = 0x7FC0DEAD, 0x7E5A  # NaN patterns: a guard word that leaks into arithmetic is visible

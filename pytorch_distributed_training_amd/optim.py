@@ -68,6 +68,8 @@ class FusedAdamW:
         # True: the data-parallel reducer already flags non-finite values bucket by bucket, on the reduced gradients
         # (parallel/dp.py attach_scaler) - no separate pass over the arena here
         self.grads_checked_by_reducer = False
+        # the data-parallel reducer that updates buckets on the communication stream as they land (attach_reducer)
+        self._bucket_reducer = None
         self.param_groups = [{"lr": lr, "initial_lr": lr}]  # scheduler-facing, mirrors torch optimizers
         self._host_lr = lr
 
@@ -80,6 +82,26 @@ class FusedAdamW:
 
     def get_lr(self) -> float:
         return self._host_lr
+
+    def attach_reducer(self, reducer) -> bool:
+        """Let the data-parallel reducer run this optimizer's update bucket by bucket on the communication stream, right
+        behind each bucket's all-reduce, so that the update of the first buckets overlaps the rest of backward instead
+        of starting after the last bucket has landed (2.3 ms for BERT-large).  Only for precisions that never skip a
+        step: with fp16's dynamic loss scale one overflowing bucket cancels the update of ALL of them, which an early
+        update could not undo.  ``PDT_ADAMW_PER_BUCKET=0`` turns it off.  True if the reducer took the job."""
+        import os
+
+        if (self.scaler.enabled or not hasattr(reducer, "set_optimizer") or not self.arena.master.is_cuda
+                or os.environ.get("PDT_ADAMW_PER_BUCKET", "1") == "0"):
+            return False
+        a = self.arena
+        reducer.set_optimizer(a.master, self.m, self.v, a.p16, self.lr, self.step_count, self.scaler.state, self.betas[0],
+                              self.betas[1], self.eps, self.weight_decay, self.correct_bias)
+        if not reducer.applies_optimizer():  # (process-group transport, wire dtype conversion, single rank)
+            reducer.clear_optimizer()
+            return False
+        self._bucket_reducer = reducer
+        return True
 
     # -- optimizer interface -----------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -111,8 +133,27 @@ class FusedAdamW:
                 else:
                     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=overflow_group)
                 check = False
-            C.adamw_step(a.master, self.m, self.v, a.grad, a.p16, self.lr, self.step_count, self.scaler.state,
-                         self.betas[0], self.betas[1], self.eps, self.weight_decay, self.correct_bias, check)
+            applied = list(self._bucket_reducer.optimizer_applied()) if self._bucket_reducer is not None else []
+            if any(applied):
+                # buckets the reducer has updated behind their all-reduce are done; the rest (left-overs that nobody
+                # completed, reduced at the end of backward) are updated here, as contiguous arena ranges
+                b, i = a.bucket_bounds, 0
+                while i < len(applied):
+                    if applied[i]:
+                        i += 1
+                        continue
+                    j = i
+                    while j < len(applied) and not applied[j]:
+                        j += 1
+                    lo, n = b[i], b[j] - b[i]
+                    C.adamw_step(a.master.narrow(0, lo, n), self.m.narrow(0, lo, n), self.v.narrow(0, lo, n),
+                                 a.grad.narrow(0, lo, n), a.p16.narrow(0, lo, n) if a.p16 is not None else None, self.lr,
+                                 self.step_count, self.scaler.state, self.betas[0], self.betas[1], self.eps,
+                                 self.weight_decay, self.correct_bias, False)
+                    i = j
+            else:
+                C.adamw_step(a.master, self.m, self.v, a.grad, a.p16, self.lr, self.step_count, self.scaler.state,
+                             self.betas[0], self.betas[1], self.eps, self.weight_decay, self.correct_bias, check)
             C.scaler_update(self.scaler.state, self.step_count, self.scaler.growth_factor,
                             self.scaler.backoff_factor, self.scaler.growth_interval, self.scaler.dynamic)
         else:

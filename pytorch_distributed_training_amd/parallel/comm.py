@@ -36,13 +36,40 @@ def backend_choice(explicit: Optional[str] = None) -> str:
     return choice
 
 
+_AGREE_ROUND: Dict[tuple, int] = {}
+
+
 def _agree(ok: bool, group, device) -> bool:
-    """True iff `ok` on every rank of `group` (decided over the already working process group)."""
+    """True iff `ok` on every rank of `group`.
+
+    Decided over the rendezvous store (host sockets only), not with a collective on the "nccl" group: a communicator
+    that just failed its self test may have left kernels of the same RCCL library stuck on the GPU, and a GPU
+    collective queued behind them would turn the fall-back decision into the hang it is there to avoid.  Every rank
+    publishes its verdict under a key of its own and reads the others' (``PDT_COMM_AGREE_S``, default 120 s); a rank that
+    cannot be heard counts as failed.  Without a reachable store the process group decides, as before."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return ok
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(flag.item())
+    ranks = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:  # noqa: BLE001 - private accessor: fall back to the collective
+        store = None
+    if store is None:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+    import datetime
+
+    rnd = _AGREE_ROUND.get(ranks, 0)
+    _AGREE_ROUND[ranks] = rnd + 1
+    prefix = f"pdt/comm_agree/{'-'.join(map(str, ranks))}/{rnd}/"
+    store.set(prefix + str(dist.get_rank()), b"1" if ok else b"0")
+    keys = [prefix + str(r) for r in ranks]
+    try:
+        store.wait(keys, datetime.timedelta(seconds=float(os.environ.get("PDT_COMM_AGREE_S", "120"))))
+    except Exception:  # noqa: BLE001 - a silent rank: nobody may use the communicator
+        return False
+    return all(store.get(k) == b"1" for k in keys)
 
 
 def self_test(comm) -> str:

@@ -147,18 +147,22 @@ class DataParallel(nn.Module):
         nb = len(arena.bucket_bounds) - 1
         if self.native_mode:
             expected = list(arena.bucket_segments)
-            seg_bucket = [s.bucket for s in arena.segments]
-            runtime.segment_done = lambda seg: self._mark(seg_bucket[seg])
+            seg_buckets = [s.buckets for s in arena.segments]
+            runtime.segment_done = lambda seg: [self._mark(b) for b in seg_buckets[seg]]
         else:
             expected = [0] * nb
             for seg in arena.segments:
                 for _, p in seg.params:
                     if p.requires_grad:
-                        expected[seg.bucket] += 1
-                        p.register_post_accumulate_grad_hook(self._make_hook(seg.bucket))
+                        for b in seg.buckets:  # (a large segment is cut into several buckets: all of them wait for it)
+                            expected[b] += 1
+                        p.register_post_accumulate_grad_hook(self._make_hook(seg.buckets))
             expected = [max(1, e) for e in expected]
         self.reducer, self.backend_label, self.rccl_comm = make_reducer(self.pg, arena, expected, True, comm_dtype,
                                                                         comm_backend)
+        self.comm_dtype = comm_dtype
+        if dist.get_rank(self.pg) == 0 and (self.world_size > 1 or os.environ.get("PDT_COMM_VERBOSE")):
+            print(self.describe(), flush=True)  # one line per data-parallel group: what a first-run log needs
         if self.world_size > 1:
             self._verify_replicas()
         if broadcast_from is not None and self.world_size > 1:
@@ -183,6 +187,26 @@ class DataParallel(nn.Module):
             raise RuntimeError(f"data-parallel replicas differ: ranks {bad} do not match rank 0 "
                                f"(arena elements / parameters / buckets / layout hash: "
                                f"{[t.tolist() for t in every]})")
+
+    def describe(self) -> str:
+        """The gradient path of this replica group in one line: transport, RCCL version and communicator size as RCCL
+        reports them, wire dtype, collective per bucket, and the buckets' sizes in backward-completion order."""
+        b = self.arena.bucket_bounds
+        mb = [round((b[i + 1] - b[i]) * 4 / 2 ** 20, 1) for i in range(len(b) - 1)]
+        version = ""
+        try:
+            from ..ops import native
+
+            v = int(native().RcclComm.rccl_version())
+            version = f" RCCL {v // 10000}.{v // 100 % 100}.{v % 100}"
+        except Exception:  # noqa: BLE001 - CPU-only build / no extension: nothing to report
+            pass
+        wire = {None: "fp32", torch.float32: "fp32", torch.float16: "fp16", torch.bfloat16: "bf16"}[self.comm_dtype]
+        ranks = dist.get_process_group_ranks(self.pg) if dist.is_initialized() else [0]
+        return (f"[dp] ranks {list(ranks)} transport {self.backend_label}{version} ncclCommCount "
+                f"{int(self.rccl_comm.comm_count()) if self.rccl_comm is not None else 'n/a'} wire {wire} "
+                f"per-bucket {os.environ.get('PDT_COMM_ALGO', 'allreduce')} | {len(mb)} buckets, {sum(mb):.0f} MB fp32 "
+                f"gradients, MB in arena order: {mb}")
 
     def attach_scaler(self, scaler) -> bool:
         """Let the reducer check every reduced bucket for inf / NaN on the communication stream (fp16 runs on the
@@ -219,9 +243,10 @@ class DataParallel(nn.Module):
                                f"(parameter sums per rank: {sums})")
 
     # -- reducer plumbing ----------------------------------------------------------------------------
-    def _make_hook(self, bucket: int):
+    def _make_hook(self, buckets):
         def hook(_p):
-            self._mark(bucket)
+            for b in buckets:
+                self._mark(b)
         return hook
 
     def _mark(self, bucket: int) -> None:

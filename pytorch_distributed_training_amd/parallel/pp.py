@@ -280,7 +280,7 @@ def run_pipeline_training(rank: int, world_size: int, cfg) -> dict:
     mesh = ParallelMesh(world_size, rank, pp=2).build_groups()
     engine = Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed, process_group=mesh.dp_group,
                     min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale,
-                    comm_backend=cfg.comm_backend)
+                    comm_backend=cfg.comm_backend, update_in_backward=False)
     model_cfg = preset(cfg.model) if not cfg.init_from else ckpt.EncoderConfig.load(cfg.init_from)
     train_ds, val_ds = build_datasets(cfg, model_cfg)
     accum, micro_bs = cfg.accumulation(engine.device, model_cfg)

@@ -120,7 +120,7 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     engine = engine or Engine(fp16=cfg.fp16, bf16=cfg.bf16, cpu=cfg.cpu, seed=cfg.seed,
                               comm_dtype={None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[cfg.comm_dtype],
                               min_bucket_mb=cfg.min_bucket_mb, init_scale=cfg.init_scale,
-                    comm_backend=cfg.comm_backend)
+                    comm_backend=cfg.comm_backend, update_in_backward=not cfg.max_grad_norm > 0)
     # rank banner, as the reference prints it on every process
     print("LOCAL_RANK: ", engine.local_process_index)
     print("DEVICE: ", engine.device)
@@ -232,14 +232,6 @@ def run_data_parallel(cfg: TrainConfig, engine: Optional[Engine] = None) -> dict
     last_metric["optimizer_steps"] = global_step
     last_metric["wall_s"] = time.perf_counter() - t_start
     return last_metric
-
-
-class _Null:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -455,3 +455,18 @@ def dp_replica_mismatch(rank, world):
     except RuntimeError as e:
         return "replicas differ" in str(e) and "[1]" in str(e)
     return False
+
+
+def cap_agreement(rank, world):
+    """Ranks that read different amounts of free HBM must end up with the same (accumulation steps, micro-batch)."""
+    import types
+
+    from pytorch_distributed_training_amd.config import TrainConfig
+    from pytorch_distributed_training_amd.launch import init_distributed
+    from pytorch_distributed_training_amd.models.config import preset
+
+    init_distributed(cpu=True)
+    cfg = TrainConfig(batch_size=4096, max_length=128)
+    fake_gpu = types.SimpleNamespace(type="cuda")  # (no index: the agreement runs over the gloo group's CPU tensors)
+    free = (200 << 30) if rank == 0 else (20 << 30)  # rank 1 shares its card with somebody
+    return cfg.accumulation(fake_gpu, preset("bert-large-cased"), free_bytes=free)

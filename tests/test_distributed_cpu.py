@@ -78,3 +78,11 @@ def test_debug_mode_guards_and_exposed_comm_timer():
 
 def test_replica_layout_is_verified_across_ranks():
     assert all(run_distributed(W.dp_replica_mismatch, 2))
+
+
+def test_micro_batch_cap_is_agreed_across_ranks():
+    """The cap is sized from each rank's own free-HBM reading; the ranks must settle on one value (the smallest)."""
+    res = run_distributed(W.cap_agreement, 2)
+    assert res[0] == res[1]
+    accum, micro = res[0]
+    assert accum * micro <= 4096 and micro < 1024  # rank 1's 20 GB decide, not rank 0's 200 GB

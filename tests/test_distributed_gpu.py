@@ -125,12 +125,10 @@ def test_eight_ranks_as_four_pipeline_pairs_reproduce_the_single_process_loss_cu
 def test_rccl_call_path_single_rank():
     """A 1-rank "nccl" (= RCCL) group with forced collectives: broadcast, bucketed all-reduce with the native
     AVG reduction on the communicator's stream, barrier - the API path the multi-GPU runs take."""
-    import subprocess
-
     code = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
-os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["PDT_TEST_PORT"],
                   PDT_FORCE_COLLECTIVES="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -160,16 +158,18 @@ t = torch.ones(4, device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dis
 dist.destroy_process_group()
 print("RCCL_PATH_OK")
 '''
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    _run_snippet(code, "RCCL_PATH_OK")
 
 
 def _run_snippet(code: str, marker: str, timeout: int = 180):
     import subprocess
 
+    from pytorch_distributed_training_amd.launch import find_free_port
+
+    # (PDT_TEST_PORT: a free rendezvous port for snippets that open a process group of their own)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       env=dict(os.environ, PDT_TEST_PORT=str(find_free_port())))
     assert marker in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
@@ -246,8 +246,8 @@ def grads(mode):
     if mode is not None:
         red, label, _ = make_reducer(None, arena, list(arena.bucket_segments), True, mode[1], comm_backend="rccl")
         assert label == "rccl"
-        seg_bucket = [s.bucket for s in arena.segments]
-        m.runtime.segment_done = lambda seg: red.mark_ready(seg_bucket[seg], 1)
+        seg_buckets = [s.buckets for s in arena.segments]
+        m.runtime.segment_done = lambda seg: [red.mark_ready(b, 1) for b in seg_buckets[seg]]
         red.begin(True)
     m(**b).loss.backward()
     if red is not None:
@@ -276,8 +276,8 @@ def overflow_flag(loss_factor):
     state = torch.tensor([1.0, 0.0, 0.0, 0.0], device="cuda")
     red.set_overflow_state(state)
     assert red.checks_overflow()
-    seg_bucket = [s.bucket for s in arena.segments]
-    m.runtime.segment_done = lambda seg: red.mark_ready(seg_bucket[seg], 1)
+    seg_buckets = [s.buckets for s in arena.segments]
+    m.runtime.segment_done = lambda seg: [red.mark_ready(b, 1) for b in seg_buckets[seg]]
     red.begin(True)
     (m(**b).loss * loss_factor).backward()
     red.finish()
@@ -289,14 +289,81 @@ print("REDUCER_NATIVE_RCCL_OK")
     _run_snippet(code, "REDUCER_NATIVE_RCCL_OK")
 
 
-def _torchrun_bench(extra, port, timeout=240):
+def test_adamw_runs_bucket_by_bucket_behind_the_all_reduces_in_bf16():
+    """bf16 run on the native communicator (1-rank group, collectives forced): the reducer applies AdamW to every bucket
+    on the communication stream right behind its all-reduce, the optimizer step only handles what is left (left-over
+    buckets) and the scaler bookkeeping.  Three steps end in bit-identical parameters, 16-bit copies and moments to
+    the run that updates the whole arena in optimizer.step(); large buckets are cut into several that all wait for
+    the same segment.  fp16 runs (dynamic loss scale: one skip decision for all buckets) refuse the hook."""
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ["PDT_FORCE_COLLECTIVES"] = "1"
+from pytorch_distributed_training_amd.models.bert import build_model
+from pytorch_distributed_training_amd.ops.arena import ParamArena
+from pytorch_distributed_training_amd.optim import FusedAdamW, LossScaler
+from pytorch_distributed_training_amd.parallel.dp import make_reducer
+from pytorch_distributed_training_amd.data.synthetic import fixed_batch
+torch.cuda.set_device(0)
+b = fixed_batch(8, 32, 512, "cuda")
+def run(per_bucket, dtype=torch.bfloat16, steps=3):
+    torch.manual_seed(0)
+    m = build_model("bert-tiny").cuda()
+    arena = ParamArena(m, torch.device("cuda"), dtype, min_bucket_elems=1 << 14, max_bucket_elems=1 << 17,
+                       tail_bucket_elems=1 << 16)
+    m.enable_native(arena, seed=1)
+    m.train()
+    red, label, _ = make_reducer(None, arena, list(arena.bucket_segments), True, None, comm_backend="rccl")
+    seg_buckets = [s.buckets for s in arena.segments]
+    assert max(len(x) for x in seg_buckets) > 1          # the embedding table is cut into several buckets
+    m.runtime.segment_done = lambda seg: [red.mark_ready(k, 1) for k in seg_buckets[seg]]
+    opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.01, scaler=LossScaler(torch.device("cuda"), enabled=dtype == torch.float16))
+    took = opt.attach_reducer(red) if per_bucket else False
+    for _ in range(steps):
+        red.begin(True)
+        m(**b).loss.backward()
+        red.finish()
+        applied = list(red.optimizer_applied())
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    return took, applied, [t.clone() for t in (arena.master, arena.p16, opt.m, opt.v, opt.step_count)]
+took, applied, a = run(True)
+assert took and sum(applied) >= len(applied) - 1 and sum(applied) >= 3, applied
+took0, applied0, ref = run(False)
+assert not took0 and not any(applied0)
+for x, y in zip(a, ref):
+    assert torch.equal(x, y)
+assert int(a[4]) == 3
+os.environ["PDT_ADAMW_PER_BUCKET"] = "0"
+assert run(True, steps=1)[0] is False
+del os.environ["PDT_ADAMW_PER_BUCKET"]
+assert run(True, torch.float16, steps=1)[0] is False
+print("ADAMW_PER_BUCKET_OK")
+'''
+    _run_snippet(code, "ADAMW_PER_BUCKET_OK")
+
+
+def _torchrun_bench(extra, port=None, timeout=240, bare=False):
+    """bench.py with two ranks: under the launcher (the driver's command line), or - `bare` - as plain
+    ``python bench.py --gpus 2`` with no launcher environment, where the script starts its own rank processes."""
     import json
     import subprocess
 
+    from pytorch_distributed_training_amd.launch import find_free_port
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    tail = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    if bare:
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port or find_free_port())] + tail
     env = dict(os.environ, PDT_HANG_DUMP="150")
+    if bare:  # no launcher environment at all: that is the point
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                  "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_USE_AGENT_STORE"):
+            env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
@@ -308,10 +375,19 @@ def test_bench_two_ranks_share_the_gpu_data_parallel_and_pipeline():
     one workgroup per tile - the Engine switches the persistent launch off): data parallel (bucket reducer staged
     through the host) and DP x 2-stage pipeline in fp16 (overflow flag agreed across the stages)."""
     assert_mode = 0  # what bench.py must report as gemm_persistent_mode for a multi-rank run
-    dp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"], 29641)
+    dp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"])
     assert dp["n_gpus"] == 2 and dp["config"]["parallelism"] == "dp2" and dp["value"] > 0
     assert dp["config"]["gemm_persistent_mode"] == assert_mode and dp["replicas_bit_equal"] is True
-    assert dp["final_loss"] == dp["final_loss"] and dp["comm_exposed_ms_per_step"] is not None
-    pp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "256", "--pp", "2", "--micro-batches", "4"], 29642)
+    assert dp["last_step_loss"] == dp["last_step_loss"] and dp["comm_exposed_ms_per_step"] is not None
+    pp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "256", "--pp", "2", "--micro-batches", "4"])
     assert pp["config"]["parallelism"].startswith("dp1 x pp2") and pp["value"] > 0
-    assert pp["final_loss"] == pp["final_loss"] and pp["config"]["global_batch"] == 512
+    assert pp["last_step_loss"] == pp["last_step_loss"] and pp["config"]["global_batch"] == 512
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """``python bench.py --gpus 2`` with no launcher environment (the reference's model-parallel script starts its own
+    ranks the same way, /root/reference/test_model_parallelism.py:331-335): the parent never touches the GPU, runs
+    torch.distributed.run with two fresh rank processes as a child and returns its status; one JSON line comes back."""
+    out = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"], bare=True)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and out["replicas_bit_equal"] is True

@@ -477,3 +477,17 @@ def test_in_memory_round_trip_with_a_transformers_model():
     with torch.no_grad():
         c = back(input_ids=ids, attention_mask=mask).logits
     torch.testing.assert_close(c, b, rtol=1e-4, atol=1e-5)
+
+
+def test_checkpoint_tags_order_numerically(tmp_path):
+    """Only the step field of a tag is zero-padded: epoch 10 must sort after epoch 9 (and be the one that is kept)."""
+    from pytorch_distributed_training_amd import checkpoint as ck
+
+    assert sorted(["00000040-10-0", "00000040-9-57", "00000039-9-56"], key=ck._tag_key) == \
+        ["00000039-9-56", "00000040-9-57", "00000040-10-0"]
+    torch.manual_seed(0)
+    model = build_model("bert-tiny")
+    for epoch, off in ((9, 57), (10, 0)):
+        ck.save_training_state(str(tmp_path), model, extra={"global_step": 40, "epoch": epoch, "micro_offset": off}, keep=1)
+    assert ck.available_tags(str(tmp_path)) == ["00000040-10-0"]  # the older one was pruned, not the newer
+    assert ck.common_tag(str(tmp_path), "") == "00000040-10-0"

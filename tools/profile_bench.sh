@@ -3,6 +3,12 @@
 #   bash tools/profile_bench.sh <name> <timed steps> [bench.py flags...]
 # writes gpurun_out/<name>_{kernel_stats,call_sites,pmc}.txt; each rocprofv3 pass is its own bounded run.
 set -u
+# (a multi-rank bench.py would have to start its ranks from a process the profiler has already attached to the GPU)
+for a in "$@"; do
+  if [ "${prev:-}" = "--gpus" ] && [ "$a" != "1" ]; then echo "this script profiles single-GPU runs only (--gpus 1)"; exit 2; fi
+  case "$a" in --gpus=1) ;; --gpus=*) echo "this script profiles single-GPU runs only (--gpus 1)"; exit 2;; esac
+  prev=$a
+done
 name=$1; steps=$2; shift 2
 export TMPDIR=/tmp
 root=$(pwd)

@@ -2,6 +2,12 @@
 # HBM bytes per kernel of one bench.py configuration: bash tools/profile_hbm.sh <name> [bench.py flags...]
 # -> gpurun_out/<name>_hbm.txt  (three bounded rocprofv3 runs: kernel trace, FETCH_SIZE, WRITE_SIZE)
 set -u
+# (a multi-rank bench.py would have to start its ranks from a process the profiler has already attached to the GPU)
+for a in "$@"; do
+  if [ "${prev:-}" = "--gpus" ] && [ "$a" != "1" ]; then echo "this script profiles single-GPU runs only (--gpus 1)"; exit 2; fi
+  case "$a" in --gpus=1) ;; --gpus=*) echo "this script profiles single-GPU runs only (--gpus 1)"; exit 2;; esac
+  prev=$a
+done
 name=$1; shift
 export TMPDIR=/tmp
 out=$(pwd)/gpurun_out
