@@ -124,6 +124,7 @@ def main() -> None:
         model = DataParallel(model, model.arena, None, comm, comm_backend=args.comm)
         eng._models[-1] = model
         optimizer.optimizer.grads_checked_by_reducer = model.attach_scaler(eng.scaler)
+        optimizer.optimizer.attach_reducer(model.reducer)  # (bf16: AdamW per bucket behind the all-reduces)
     sched = get_linear_schedule_with_warmup(optimizer, 100, 10000)
     model.train()
     micro = args.batch // args.accum
@@ -221,7 +222,8 @@ def main() -> None:
                        "gemm_persistent_mode": _persist_mode(),
                        "hip_graph": bool(args.graph),
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if eng.device.type == "cuda" else None,
-                       "optimizer": "fused AdamW + dynamic loss scale",
+                       "optimizer": "fused AdamW + dynamic loss scale" if args.dtype == "fp16" else "fused AdamW",
+                       "adamw_per_bucket": getattr(optimizer.optimizer, "_bucket_reducer", None) is not None,
                        "dropout": 0.1},
         }))
     if dist.is_initialized():

@@ -213,6 +213,8 @@ class DataParallel(nn.Module):
         framework's own communicator).  True if it will, i.e. the optimizer can skip its own pass over the arena."""
         if scaler is None or not scaler.enabled or not hasattr(self.reducer, "set_overflow_state"):
             return False
+        if os.environ.get("PDT_BUCKET_OVERFLOW_CHECK", "1") == "0":  # one pass over the arena in the optimizer instead
+            return False
         self.reducer.set_overflow_state(scaler.state)
         return bool(self.reducer.checks_overflow())
 
