@@ -183,10 +183,13 @@ class _TowerRank(nn.Module):
         return rt
 
 
-def _p2p(ops):
-    from ..parallel.pp import _p2p as run
+def _p2p(ops, mesh, engine):
+    """Activations and their gradients between the two ranks of a replica: device to device over the replica's own
+    RCCL communicator, like the pipeline layout (the reference moves them with ``.to(device)``,
+    /root/reference/test_model_parallelism.py:127-143); through the process group where there is none."""
+    from ..parallel.pp import _p2p as run, replica_comm
 
-    run(ops)
+    run(ops, replica_comm(mesh, engine), mesh.pp)
 
 
 def tower_step(module, mesh, engine, batch, train: bool = True):
@@ -225,13 +228,13 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
         if mesh.stage == 0:
             b1 = inner.bert_1
             emb = b1.get_input_embeddings()(ids.reshape(-1)[tok] if packed else ids)
-            _p2p([dist.P2POp(dist.isend, emb.detach().to(adt).contiguous(), peer1)])
+            _p2p([dist.P2POp(dist.isend, emb.detach().to(adt).contiguous(), peer1)], mesh, engine)
             # tower 1 reads a detached copy, so the embedding lookup is differentiated ONCE, at the very end,
             # with the sum of this rank's and the peer's gradient
             emb_in = emb.detach().requires_grad_() if train else emb
             h1 = run_towers([b1], emb_in)[0]
             s23 = torch.empty(B, 1, H, dtype=torch.float32, device=dev)
-            _p2p([dist.P2POp(dist.irecv, s23, peer1)])
+            _p2p([dist.P2POp(dist.irecv, s23, peer1)], mesh, engine)
             if train:
                 s23.requires_grad_()
             first = (h1.float() + s23) / 3.0
@@ -248,7 +251,7 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
             # tower-1 / head gradients; d(s23) goes to the second rank, which answers with d(embedding)
             loss.backward()
             d_emb = torch.empty(*emb_shape, dtype=adt, device=dev)
-            _p2p([dist.P2POp(dist.isend, s23.grad.contiguous(), peer1), dist.P2POp(dist.irecv, d_emb, peer1)])
+            _p2p([dist.P2POp(dist.isend, s23.grad.contiguous(), peer1), dist.P2POp(dist.irecv, d_emb, peer1)], mesh, engine)
             emb.backward(emb_in.grad.to(emb.dtype) + d_emb.to(emb.dtype))
             if rt is not None:
                 rt.release()
@@ -256,22 +259,22 @@ def tower_step(module, mesh, engine, batch, train: bool = True):
                 dp.finish_backward()  # the embedding bucket (and anything unused) is reduced here; then the join
             return out.loss.detach(), out.logits
         emb = torch.empty(*emb_shape, dtype=adt, device=dev)
-        _p2p([dist.P2POp(dist.irecv, emb, peer0)])
+        _p2p([dist.P2POp(dist.irecv, emb, peer0)], mesh, engine)
         if train:
             emb.requires_grad_()
         hs = run_towers(inner.towers(), emb)
         s = hs[0].float() + hs[1].float()
-        _p2p([dist.P2POp(dist.isend, s.detach().contiguous(), peer0)])
+        _p2p([dist.P2POp(dist.isend, s.detach().contiguous(), peer0)], mesh, engine)
         if not train:
             return None, None
         ds = torch.empty_like(s)
-        _p2p([dist.P2POp(dist.irecv, ds, peer0)])
+        _p2p([dist.P2POp(dist.irecv, ds, peer0)], mesh, engine)
         if dp is not None:
             dp.prepare_backward()
         s.backward(ds)
         if dp is not None:
             dp.finish_backward()
-        _p2p([dist.P2POp(dist.isend, emb.grad.contiguous(), peer0)])
+        _p2p([dist.P2POp(dist.isend, emb.grad.contiguous(), peer0)], mesh, engine)
         return None, None
 
 

@@ -124,6 +124,19 @@ def _p2p(ops, comm=None, pp: int = 2) -> None:
         w.wait()
 
 
+def replica_comm(mesh: ParallelMesh, engine):
+    """The framework's own RCCL communicator over the ranks of this replica (its model-parallel group), or None where
+    the point-to-point traffic goes through the process group: CPU / gloo runs, ``--comm-backend c10d``, a communicator
+    that failed its self test.  Collective over the replica the first time; remembered on the mesh afterwards."""
+    if not hasattr(mesh, "_replica_comm"):
+        comm = None
+        if (engine.device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl"
+                and backend_choice(getattr(engine, "comm_backend", None)) == "rccl"):
+            comm = create_rccl_comm(mesh.pp_group, engine.device)
+        mesh._replica_comm = comm
+    return mesh._replica_comm
+
+
 class PipelineStage:
     """Driver of one rank of a 2-stage pipeline replica."""
 
@@ -146,10 +159,7 @@ class PipelineStage:
         # unpadded execution needs the native kernels on both stages; both ranks of a replica decide alike (same
         # build, same device type, same precision mode)
         self.packed = getattr(inner, "runtime", None) is not None and engine.device.type == "cuda"
-        self.comm = None
-        if (engine.device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl"
-                and backend_choice(getattr(engine, "comm_backend", None)) == "rccl"):
-            self.comm = create_rccl_comm(mesh.pp_group, engine.device)
+        self.comm = replica_comm(mesh, engine)
 
     # -- communication -------------------------------------------------------------------------------
     def _buf(self, chunk: Dict[str, torch.Tensor]) -> torch.Tensor:

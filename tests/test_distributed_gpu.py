@@ -12,6 +12,19 @@ from pytorch_distributed_training_amd.testing import run_distributed  # noqa: E4
 pytestmark = pytest.mark.gpu
 
 
+# bert-tiny curves (losses ~0.7, lr 2e-3 - 100x the reference's).  A run with ``-s`` prints what the layouts achieve:
+# 8e-7 ... 1.2e-5 on MI355X for every layout below; the tolerance leaves a factor of 15 over the worst of them
+TOL_TINY = 2e-4
+
+
+def _maxdiff(name, got, ref):
+    """Largest |loss difference| of two curves; printed so that a run with ``-s`` shows what the tolerances leave."""
+    assert len(got) == len(ref), (name, got, ref)
+    d = max(abs(a - b) for a, b in zip(got, ref))
+    print(f"PARITY {name}: max |dloss| {d:.2e} over {len(ref)} steps")
+    return d
+
+
 def test_dp_native_gradients_match_big_batch_two_ranks_one_gpu():
     for r in run_distributed(W.gpu_dp_native, 2):
         assert r["err"] < 2e-2 and r["same"]
@@ -41,8 +54,7 @@ def test_pipeline_native_loss_curve(world):
     res = run_distributed(W.gpu_pipeline_recipe, world, args=("pipeline",))
     got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
     assert len(got) == len(ref) == steps, (got, ref)
-    for a, b in zip(got, ref):
-        assert abs(a - b) < 2e-2, (got, ref)
+    assert _maxdiff(f"pipeline nodrop world {world}", got, ref) < TOL_TINY, (got, ref)
     assert all(r["replicas_bit_equal"] in (True, None) for r in res)
 
 
@@ -57,7 +69,7 @@ def test_pipeline_hands_packed_rows_across_the_link():
     packed, padded = runs[True], runs[False]
     assert packed["packed"] is True and padded["packed"] is False
     assert len(packed["losses"]) == len(padded["losses"]) == 6
-    assert max(abs(a - b) for a, b in zip(packed["losses"], padded["losses"])) < 1.5e-2, (packed["losses"], padded["losses"])
+    assert _maxdiff("packed vs padded", packed["losses"], padded["losses"]) < TOL_TINY, (packed["losses"], padded["losses"])
     assert packed["link_mb"] < 0.9 * padded["link_mb"], (packed["link_mb"], padded["link_mb"])
 
 
@@ -72,8 +84,7 @@ def test_tower_parallel_native_loss_curve(world):
     res = run_distributed(W.gpu_pipeline_recipe, world, args=("towers", world == 4))
     got = [r for r in res if r["stage"] == 0 and r["replica"] == 0][0]["losses"][:4]
     assert len(got) == 4
-    for a, b in zip(got, ref):
-        assert abs(a - b) < 2e-2, (got, ref)
+    assert _maxdiff(f"towers nodrop world {world}", got, ref) < TOL_TINY, (got, ref)
     if world == 4:
         assert all(r["replicas_bit_equal"] is True for r in res)
 
@@ -85,16 +96,16 @@ def test_dropout_masks_follow_the_sample_across_parallel_layouts():
     global batch to fp16 tolerance - rank- or micro-batch-keyed masks differ by ~0.05 in the loss from step one."""
     ref = W.gpu_single_reference("dp", steps=6, replicas=2, model="bert-tiny")
     for got in run_distributed(W.gpu_dp_dropout, 2):
-        assert len(got) == 6 and max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+        assert _maxdiff("dp2 dropout", got, ref) < TOL_TINY, (got, ref)
     for world, steps in ((2, 6), (4, 4)):
         ref = W.gpu_single_reference("pipeline", steps=steps, replicas=world // 2, model="bert-tiny")
         res = run_distributed(W.gpu_pipeline_recipe, world, args=("pipeline", False, "bert-tiny"))
         got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
-        assert len(got) == steps and max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (world, got, ref)
+        assert _maxdiff(f"pipeline dropout world {world}", got, ref) < TOL_TINY, (world, got, ref)
     ref = W.gpu_single_reference("towers", steps=4, replicas=2, model="bert-tiny")
     res = run_distributed(W.gpu_pipeline_recipe, 4, args=("towers", False, "bert-tiny"))
     got = [r for r in res if r["stage"] == 0 and r["replica"] == 0][0]["losses"][:4]
-    assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+    assert _maxdiff("towers dropout world 4", got, ref) < TOL_TINY, (got, ref)
 
 
 def test_pipeline_stages_skip_overflowed_steps_together():
@@ -106,7 +117,7 @@ def test_pipeline_stages_skip_overflowed_steps_together():
     assert max(abs(a - b) for a, b in zip(ref, calm)) > 1e-3, (ref, calm)  # updates were skipped
     res = run_distributed(W.gpu_pipeline_recipe, 2, args=("pipeline", False, "bert-tiny-nodrop", True, 64, 2e-3, 2.0 ** 24))
     got = [r for r in res if r["stage"] == 1][0]["losses"]
-    assert len(got) == 6 and max(abs(a - b) for a, b in zip(got, ref)) < 2e-2, (got, ref)
+    assert _maxdiff("pipeline overflowing scale", got, ref) < TOL_TINY, (got, ref)
 
 
 def test_eight_ranks_as_four_pipeline_pairs_reproduce_the_single_process_loss_curve():
@@ -117,8 +128,20 @@ def test_eight_ranks_as_four_pipeline_pairs_reproduce_the_single_process_loss_cu
     ref = W.gpu_single_reference("pipeline", steps=6, replicas=4, model="bert-tiny", examples=256)
     res = run_distributed(W.gpu_pipeline_recipe, 8, args=("pipeline", False, "bert-tiny", True, 256))
     got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"]
-    assert len(got) == len(ref) == 6, (got, ref)
-    assert max(abs(a - b) for a, b in zip(got, ref)) < 1.5e-2, (got, ref)
+    assert _maxdiff("8 ranks = 4 x pp2", got, ref) < TOL_TINY, (got, ref)
+    assert all(r["replicas_bit_equal"] is True for r in res)
+
+
+def test_bert_base_two_replicas_of_two_stages_match_one_process():
+    """Real model size in the driver-run suite: bert-base-cased (110 M parameters), 4 ranks = 2 data-parallel replicas x 2
+    pipeline stages on the one GPU, fp16, dropout 0.1 on, the reference's learning-rate scale: four optimizer steps on a
+    global batch of 32 reproduce the loss curve of ONE process on that batch to 5e-4 (the losses are ~0.7; fp16
+    activations crossing the link and a different summation order of the gradient are all that differs), and the
+    replicas of each stage stay bit-identical."""
+    ref = W.gpu_single_reference("pipeline", steps=4, replicas=2, model="bert-base-cased", examples=128, lr=5e-5)
+    res = run_distributed(W.gpu_pipeline_recipe, 4, args=("pipeline", False, "bert-base-cased", True, 128, 5e-5))
+    got = [r for r in res if r["stage"] == 1 and r["replica"] == 0][0]["losses"][:4]
+    assert _maxdiff("bert-base 2 x pp2", got, ref) <= 5e-4, (got, ref)
     assert all(r["replicas_bit_equal"] is True for r in res)
 
 
