@@ -242,7 +242,7 @@ class Engine:
                     st.enter_context(m.no_sync())
             yield
 
-    def accumulate(self, model: nn.Module, batches, overlap: Optional[bool] = None):
+    def accumulate(self, model: nn.Module, batches, overlap: Optional[bool] = None, threaded: Optional[bool] = None):
         """Forward + backward of one accumulation window (`batches` = its micro-batches, loss / len(batches) each, the
         gradient all-reduce armed for the last one only); returns the detached per-micro-batch losses.
 
@@ -287,7 +287,14 @@ class Engine:
             while len(self._alt_streams) < ns - 1:
                 self._alt_streams.append(torch.cuda.Stream(device=self.device))
             streams = [main] + self._alt_streams[:ns - 1]
-            start = torch.cuda.Event()
+            # The window's events come from a pool that lives as long as the engine and are re-recorded every window:
+            # nothing is created or destroyed per micro-batch, and - what a hipGraph capture of the window depends on -
+            # no event that a capturing stream has recorded is destroyed before the capture ends (utils/graph.py).
+            if getattr(self, "_window_events", None) is None:
+                self._window_events = []
+            while len(self._window_events) < n + ns:
+                self._window_events.append(torch.cuda.Event())
+            start, done_ev, tail_ev = self._window_events[0], self._window_events[1:n + 1], self._window_events[n + 1:n + ns]
             start.record(main)
             for st in streams[1:]:
                 st.wait_event(start)  # parameters / batches produced on the caller's stream so far
@@ -324,7 +331,10 @@ class Engine:
                 from concurrent.futures import ThreadPoolExecutor
 
                 self._fwd_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="pdt-forward")
-            threaded = os.environ.get("PDT_OVERLAP_THREAD", "1") != "0"
+            # (threaded=False: everything is issued from the calling thread - what a hipGraph capture of the window
+            # needs, see utils/graph.py; the streams still overlap on the GPU)
+            if threaded is None:
+                threaded = os.environ.get("PDT_OVERLAP_THREAD", "1") != "0"
             from .ops import native as _native
 
             defer_ok = os.environ.get("PDT_WGRAD_DEFER", "1") != "0"
@@ -383,14 +393,13 @@ class Engine:
                             _native().wgrad_join()
                     if dual and i == n - 1:
                         rt.arena.merge_alt()  # (segments that no node of the last backward reported)
-                    done[i] = torch.cuda.Event()
+                    done[i] = done_ev[i]
                     done[i].record(s)
                 losses.append(cur[0].loss.detach())
                 cur = nxt.result() if (threaded and nxt is not None) else nxt
             if dual:
                 rt.lane = 0
-            for st in streams[1:]:  # the caller's stream continues after everything on the other streams
-                tail = torch.cuda.Event()
+            for st, tail in zip(streams[1:], tail_ev):  # the caller's stream continues after everything on the other streams
                 tail.record(st)
                 main.wait_event(tail)
             return losses

@@ -23,9 +23,25 @@ all-reduces are issued through c10d, which owns its own stream and work objects)
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
+
+# Why the multi-stream accumulation window (Engine.accumulate: micro-batch i on stream i % 3, two gradient lanes, the
+# weight-gradient lane) is not captured by default.  Measured on ROCm 7.2 / PyTorch 2.10 (bench/dev/graph_window_capture.py,
+# BERT-large, 12 x 8 samples): the capture itself goes through - every launch issued from ONE host thread, so a second
+# thread adding nodes to the graph is ruled out - and the process then dies with SIGSEGV inside
+# torch.cuda.CUDAGraph.capture_end() (hipStreamEndCapture / instantiation) on the capturing thread.  The one-stream window
+# with the same kernels, the same weight-gradient fork / join per layer and as many nodes captures and replays, so the
+# crash belongs to the cross-stream part of the graph.  One difference of that part was found by reading the code and is
+# removed: the window used to create its fork / join events per call and drop them when accumulate() returned, i.e.
+# BEFORE the capture ended, while the capturing streams still list them; the events now live in a pool owned by the
+# engine.  Whether that was the cause has not been re-measured (bench/dev/hip_capture_event_destroy.cpp is the
+# stand-alone experiment for it), so the overlapped capture stays behind an explicit opt-in.
+OVERLAP_REFUSAL = ("capturing the multi-stream accumulation window crashed inside hipStreamEndCapture on ROCm 7.2 "
+                   "(see utils/graph.py); GraphedStep captures the one-stream window (window='plain'). "
+                   "PDT_GRAPH_OVERLAP_WINDOW=1 tries the overlapped capture anyway.")
 
 
 class GraphedStep:
@@ -37,14 +53,21 @@ class GraphedStep:
     """
 
     def __init__(self, engine, model, optimizer, warmup: int = 3, step_optimizer: bool = True,
-                 loss_fn: Optional[Callable] = None):
+                 loss_fn: Optional[Callable] = None, window: str = "plain"):
+        self.engine, self.model, self.optimizer = engine, model, optimizer
+        self.warmup, self.step_optimizer = max(1, warmup), step_optimizer
+        self.loss_fn = loss_fn
+        if window not in ("plain", "overlap"):
+            raise ValueError("window is 'plain' (micro-batches one after the other on one stream) or 'overlap'")
+        if window == "overlap" and loss_fn is not None:
+            raise ValueError("the overlapped window computes the model's own loss")
+        if window == "overlap" and os.environ.get("PDT_GRAPH_OVERLAP_WINDOW") != "1":
+            raise RuntimeError(OVERLAP_REFUSAL)
+        self.window = window
         if engine.num_processes != 1:
             raise RuntimeError("GraphedStep captures single-process steps only")
         if engine.device.type != "cuda":
             raise RuntimeError("GraphedStep needs a GPU")
-        self.engine, self.model, self.optimizer = engine, model, optimizer
-        self.warmup, self.step_optimizer = max(1, warmup), step_optimizer
-        self.loss_fn = loss_fn
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static: Optional[list] = None
         self.static_loss: Optional[torch.Tensor] = None
@@ -60,6 +83,14 @@ class GraphedStep:
             rt.rng_state_global[1:2].add_(1)  # (the stream of batches that carry sample ids)
         n = len(self.static)
         loss = None
+        if self.window == "overlap" and n > 1:
+            # Engine.accumulate's multi-stream window (the streams fork from and join the capturing stream), with every
+            # launch issued from THIS thread: no second host thread may add nodes to the graph while it is captured
+            loss = self.engine.accumulate(self.model, self.static, overlap=True, threaded=False)[-1]
+            if self.step_optimizer:
+                self.optimizer.step()
+                self.optimizer.zero_grad()
+            return loss.detach()
         for mb in self.static:
             out = self.model(**mb)
             loss = out.loss if self.loss_fn is None else self.loss_fn(out, mb)

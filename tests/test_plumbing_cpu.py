@@ -491,3 +491,25 @@ def test_checkpoint_tags_order_numerically(tmp_path):
         ck.save_training_state(str(tmp_path), model, extra={"global_step": 40, "epoch": epoch, "micro_offset": off}, keep=1)
     assert ck.available_tags(str(tmp_path)) == ["00000040-10-0"]  # the older one was pruned, not the newer
     assert ck.common_tag(str(tmp_path), "") == "00000040-10-0"
+
+
+def test_graphed_step_refuses_the_overlapped_window_without_the_opt_in(monkeypatch):
+    """The multi-stream accumulation window crashed inside hipStreamEndCapture when captured (utils/graph.py has the
+    findings): GraphedStep(window="overlap") says so instead of crashing unless PDT_GRAPH_OVERLAP_WINDOW=1 is set, and
+    rejects unknown window names and a custom loss for the overlapped window."""
+    import types
+
+    from pytorch_distributed_training_amd.utils.graph import OVERLAP_REFUSAL, GraphedStep
+
+    eng = types.SimpleNamespace(num_processes=1, device=torch.device("cpu"))
+    monkeypatch.delenv("PDT_GRAPH_OVERLAP_WINDOW", raising=False)
+    with pytest.raises(RuntimeError) as e:
+        GraphedStep(eng, None, None, window="overlap")
+    assert str(e.value) == OVERLAP_REFUSAL and "hipStreamEndCapture" in OVERLAP_REFUSAL
+    with pytest.raises(ValueError):
+        GraphedStep(eng, None, None, window="both")
+    with pytest.raises(ValueError):
+        GraphedStep(eng, None, None, window="overlap", loss_fn=lambda out, mb: out.loss)
+    monkeypatch.setenv("PDT_GRAPH_OVERLAP_WINDOW", "1")
+    with pytest.raises(RuntimeError, match="needs a GPU"):  # past the refusal; this fake engine has no GPU
+        GraphedStep(eng, None, None, window="overlap")
