@@ -46,6 +46,12 @@ def _sources():
     return hip, cpp, hdr
 
 
+# attention.hip writes its packed fp32 math as explicit vector operations; the SLP vectoriser on top of that pairs up the
+# scalar adds of the DPP row reductions (v_mov_b32_dpp + v_pk_add_f32, 6 instructions per 4 values and step) where the
+# un-paired adds fold into v_add_f32_dpp (4 instructions)
+PER_SOURCE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
 def _stamp(paths, flags):
     h = hashlib.sha1(" ".join(flags).encode())
     for p in paths:
@@ -88,8 +94,9 @@ def build(jobs: int = 8, verbose: bool = False, force: bool = False, kernel_defi
     tasks = []
     for s in hip:
         obj = os.path.join(BUILD, os.path.basename(s) + ".o")
-        cmd = [hipcc] + dev_flags + ["-c", s, "-o", obj]
-        tasks.append((s, obj, cmd, _stamp([s] + hdr, dev_flags)))
+        flags = dev_flags + PER_SOURCE_FLAGS.get(os.path.basename(s), [])
+        cmd = [hipcc] + flags + ["-c", s, "-o", obj]
+        tasks.append((s, obj, cmd, _stamp([s] + hdr, flags)))
     for s in cpp:
         obj = os.path.join(BUILD, os.path.basename(s) + ".o")
         cmd = [hipcc] + host_flags + ["-c", s, "-o", obj]

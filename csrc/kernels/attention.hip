@@ -101,12 +101,35 @@ __device__ __forceinline__ short8 tr_frag(const char* img, int r0, int db, int l
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
+// The per-score arithmetic of these kernels is written on whole float4v accumulator tiles (scale + mask, subtract the
+// maximum, dropout factor, dS = P * (dP - delta)): element-wise operations on 4-vectors become v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32, two elements per instruction, and pairs of results are converted with one
+// v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32.  Only exp2 and the dropout hash stay per element.  (This file is built without
+// the SLP vectoriser, see build_ext.py: it would also pair up the adds of the DPP row reductions, which then cost a
+// v_mov_b32_dpp each instead of folding into v_add_f32_dpp.)
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <typename T> struct Pk2;
+template <> struct Pk2<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
+template <> struct Pk2<__bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
+template <typename T>
+__device__ __forceinline__ int cvt_pk(float lo, float hi) {  // two fp32 -> one dword of two 16-bit values (round to nearest even)
+  return __builtin_bit_cast(int, __builtin_convertvector(float2v{lo, hi}, typename Pk2<T>::type));
+}
+__device__ __forceinline__ float4v splat4(float v) { return float4v{v, v, v, v}; }
+// A 4-vector whose elements are consumed one by one (exp2 of each) would be taken apart by the optimiser BEFORE the
+// operation that produced it ("extract of a vector op = scalar op of the extracts"), i.e. four v_sub_f32 instead of two
+// v_pk_add_f32.  Passing the two halves through an empty asm statement as 64-bit operands keeps the producing operation
+// packed; it emits nothing.
+__device__ __forceinline__ float4v packed4(float4v v) {
+  float2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+  asm("" : "+v"(lo));
+  asm("" : "+v"(hi));
+  return float4v{lo[0], lo[1], hi[0], hi[1]};
+}
 template <typename T>
 __device__ __forceinline__ short8 pack_pair(const float4v& a, const float4v& b) {
-  short8 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { r[j] = Half16<T>::from_f(a[j]); r[4 + j] = Half16<T>::from_f(b[j]); }
-  return r;
+  const int4v r = {cvt_pk<T>(a[0], a[1]), cvt_pk<T>(a[2], a[3]), cvt_pk<T>(b[0], b[1]), cvt_pk<T>(b[2], b[3])};
+  return __builtin_bit_cast(short8, r);
 }
 // lane's 8 k-values of row (lane&15) of a row-major global matrix, k-step ks: B-operand style fragment
 template <typename T>
@@ -134,10 +157,8 @@ __device__ __forceinline__ void store_tile16x64(T* row, const float4v (&t)[4], f
   int2v pk[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) {
-    short4v h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h[r] = Half16<T>::from_f(t[db][r] * mul);
-    pk[db] = __builtin_bit_cast(int2v, h);
+    const float4v v = t[db] * mul;
+    pk[db] = int2v{cvt_pk<T>(v[0], v[1]), cvt_pk<T>(v[2], v[3])};
   }
   const bool odd = g & 1;  // even g keeps blocks 0 and 2 and receives its neighbour's; odd g keeps 1 and 3
   const int2v own0 = odd ? pk[1] : pk[0], own1 = odd ? pk[3] : pk[2];
@@ -218,7 +239,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   constexpr bool drop = DROP;
 
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
+  float4v l4 = {0.f, 0.f, 0.f, 0.f};  // running sum, one partial per accumulator register
+  const float4v k2v = splat4(k2);
   float4v o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -250,8 +273,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
           acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 0, lane), qf0, acc);
           acc = Half16<T>::mfma(row_frag(kimg, kb * 16, 1, lane), qf1, acc);
           const float4v mb = *reinterpret_cast<const float4v*>(mbias + c0 + kb * 16 + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { acc[r] = fmaf(acc[r], k2, mb[r]); cmax = fmaxf(cmax, acc[r]); }
+          acc = acc * k2v + mb;
+          cmax = fmaxf(fmaxf(cmax, acc[0]), fmaxf(fmaxf(acc[1], acc[2]), acc[3]));
           s[kb] = acc;
         }
       }
@@ -260,7 +283,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       const float m_use = m_new == -INFINITY ? 0.f : m_new;  // all keys so far masked: exp2(-inf - 0) = 0
       const float alpha = __builtin_amdgcn_exp2f(m - m_use);
       m = m_new;
-      l *= alpha;
+      l4 *= alpha;
+      const float4v nm4 = splat4(-m_use);  // (packed fp32 has add / mul / fma: subtractions are additions of a negated term)
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] *= alpha;
 #pragma unroll
@@ -268,14 +292,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         if (FULL || pb < nb) {
 #pragma unroll
           for (int hb = 0; hb < 2; ++hb) {
+            float4v p = packed4(s[2 * pb + hb] + nm4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float p = __builtin_amdgcn_exp2f(s[2 * pb + hb][r] - m_use);
-              l += p;
-              if (drop)
-                p = attn_keep(rseed, kmul0 + (uint32_t)(c0 + pb * 32 + hb * 16 + r) * ATT_GOLD, thr_hi) ? p * a.drop_scale : 0.f;
-              s[2 * pb + hb][r] = p;
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+            l4 += p;
+            if (drop) {
+              float4v keep;  // drop_scale for the kept probabilities, 0 for the dropped ones
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                keep[r] = attn_keep(rseed, kmul0 + (uint32_t)(c0 + pb * 32 + hb * 16 + r) * ATT_GOLD, thr_hi) ? a.drop_scale : 0.f;
+              p *= keep;
             }
+            s[2 * pb + hb] = p;
           }
           const short8 pf = pack_pair<T>(s[2 * pb], s[2 * pb + 1]);
 #pragma unroll
@@ -286,7 +314,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     if (nb == ATT_CHUNK / 32) chunk(std::true_type{}); else chunk(std::false_type{});
   }
   if (!active) return;
-  l = quad_sum(l);
+  const float l = quad_sum((l4[0] + l4[1]) + (l4[2] + l4[3]));
   const float inv = l > 0.f ? 1.0f / l : 0.f;
   // a row whose keys are all masked has no probability mass: lse = +inf makes every recomputed p exactly 0
   if (g == 0 && q < S) a.lse[(size_t)bh * SM + q] = l > 0.f ? (m + __log2f(l)) * (1.0f / LOG2E) : INFINITY;
@@ -356,6 +384,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, fl
   const uint32_t rseed = attn_row_seed(drop_key(a.rng), drop_sample(a.rng, b) * a.A + h, q), thr_hi = attn_thr_hi(a.drop_thr);
   const uint32_t kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
   const bool drop = a.drop_thr != 0;
+  const float4v k2v = splat4(k2), nlse4 = splat4(-lse2q), nd4 = splat4(ndelta);
   float4v dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dq[db] = float4v{0.f, 0.f, 0.f, 0.f};
@@ -378,14 +407,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a, fl
           dp = Half16<T>::mfma(row_frag(vimg, kb16, 0, lane), df0, dp);
           dp = Half16<T>::mfma(row_frag(vimg, kb16, 1, lane), df1, dp);
           const float4v mb = *reinterpret_cast<const float4v*>(mbias + c0 + kb16 + 4 * g);
+          float4v ps = packed4(sc * k2v + (mb + nlse4));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ps = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb[r] - lse2q));
-            float e = dp[r] + ndelta;
-            if (drop)
-              e = attn_keep(rseed, kmul0 + (uint32_t)(c0 + kb16 + r) * ATT_GOLD, thr_hi) ? fmaf(dp[r], a.drop_scale, ndelta) : ndelta;
-            ds[hb][r] = ps * e;
+          for (int r = 0; r < 4; ++r) ps[r] = __builtin_amdgcn_exp2f(ps[r]);
+          float4v e = dp + nd4;
+          if (drop) {
+            float4v keep;  // drop_scale for the kept probabilities, 0 for the dropped ones
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              keep[r] = attn_keep(rseed, kmul0 + (uint32_t)(c0 + kb16 + r) * ATT_GOLD, thr_hi) ? a.drop_scale : 0.f;
+            e = dp * keep + nd4;
           }
+          ds[hb] = ps * e;
         }
         const short8 dsf = pack_pair<T>(ds[0], ds[1]);
 #pragma unroll
@@ -448,8 +481,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, f
   for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
   if (blk_active) {
     for (int i = tid; i < nqb * 32; i += ATT_THREADS) {
-      // log2-domain lse, +inf for the padding rows (p = 0); delta pre-multiplied by -scale
-      lse_s[i] = i < S ? a.lse[(size_t)bh * SM + i] * LOG2E : INFINITY;
+      // NEGATED log2-domain lse (it is only ever subtracted), -inf for the padding rows (p = 0); delta pre-multiplied by -scale
+      lse_s[i] = i < S ? -a.lse[(size_t)bh * SM + i] * LOG2E : -INFINITY;
       del_s[i] = i < S ? -a.scale * a.delta[(size_t)bh * SM + i] : 0.f;
       seed_s[i] = attn_row_seed(dk, drop_sample(a.rng, b) * a.A + h, i);
     }
@@ -457,7 +490,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, f
     const short8 vf0 = gfrag<T>(base + 2 * a.H, kc, ld, 0, lane), vf1 = gfrag<T>(base + 2 * a.H, kc, ld, 1, lane);
     const float mb = (key < S && (a.cu || a.mask[(size_t)b * SM + kc] != 0)) ? 0.f : -INFINITY;
     const uint32_t kmul = (uint32_t)key * ATT_GOLD, thr_hi = attn_thr_hi(a.drop_thr);
-    const float k2 = a.scale * LOG2E, dsc2 = a.drop_scale * a.scale;
+    const float k2 = a.scale * LOG2E;
+    const float4v k2v = splat4(k2), mb4 = splat4(mb);
     const bool drop = a.drop_thr != 0;
     // chunk c0 of the queries and of dO into image pair `buf`
     auto stage = [&](int c0, int buf) {
@@ -487,18 +521,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(AttnArgs a, f
             const float4v ls = *reinterpret_cast<const float4v*>(lse_s + c0 + q16 + 4 * g);
             const float4v nde = *reinterpret_cast<const float4v*>(del_s + c0 + q16 + 4 * g);
             const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + c0 + q16 + 4 * g);
+            float4v p = packed4(sc * k2v + (mb4 + ls));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb - ls[r]));
-              float pd = p, e = fmaf(dp[r], a.scale, nde[r]);
-              if (drop) {
-                const bool keep = attn_keep(sd[r], kmul, thr_hi);
-                pd = keep ? p * a.drop_scale : 0.f;
-                e = keep ? fmaf(dp[r], dsc2, nde[r]) : nde[r];
-              }
-              pp[hb][r] = pd;
-              ds[hb][r] = p * e;
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+            float4v pd = p, e = dp * a.scale + nde;
+            if (drop) {
+              float4v keep;  // drop_scale for the kept probabilities, 0 for the dropped ones
+#pragma unroll
+              for (int r = 0; r < 4; ++r) keep[r] = attn_keep(sd[r], kmul, thr_hi) ? a.drop_scale : 0.f;
+              pd = p * keep;
+              e = dp * (keep * a.scale) + nde;
             }
+            pp[hb] = pd;
+            ds[hb] = p * e;
           }
           const short8 pf = pack_pair<T>(pp[0], pp[1]);
           const short8 dsf = pack_pair<T>(ds[0], ds[1]);
@@ -629,8 +664,8 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
     __builtin_amdgcn_sched_barrier(0);
     if (tid < SMAX) {
       mbias[tid] = (tid < S && mask_raw != 0) ? 0.f : -INFINITY;
-      // log2-domain lse; +inf for the padding rows makes their recomputed probabilities exactly 0
-      lse_s[tid] = tid < S ? lse_raw * LOG2E : INFINITY;
+      // NEGATED log2-domain lse (it is only ever subtracted); -inf for the padding rows makes their recomputed probabilities exactly 0
+      lse_s[tid] = tid < S ? -lse_raw * LOG2E : -INFINITY;
       seed_s[tid] = attn_row_seed(dk, drop_sample(a.rng, b) * a.A + h, tid);
     }
     float d = 0.f;
@@ -660,8 +695,9 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   if (r0 < S && !PDT_ATT_NOCOMPUTE) {
     const int q = r0 + lm;
     // exp2(score2 + mask - lse2q) = p * scale: the softmax scale of dS is folded into the exponent
-    const float lse2q = lse_s[q] - __log2f(a.scale), ndelta = -del_s[q];
+    const float lse2q = -lse_s[q] - __log2f(a.scale), ndelta = -del_s[q];
     const uint32_t rseed = seed_s[q], kmul0 = (uint32_t)(4 * g) * ATT_GOLD;
+    const float4v k2v = splat4(k2), nlse4 = splat4(-lse2q), nd4 = splat4(ndelta);
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
       if (pb < npb) {
@@ -675,14 +711,18 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
           dp = Half16<T>::mfma(row_frag(img1, kb16, 0, lane), df0, dp);
           dp = Half16<T>::mfma(row_frag(img1, kb16, 1, lane), df1, dp);
           const float4v mb = *reinterpret_cast<const float4v*>(mbias + kb16 + 4 * g);
+          float4v ps = packed4(sc * k2v + (mb + nlse4));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float ps = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mb[r] - lse2q));
-            float e = dp[r] + ndelta;
-            if (drop)
-              e = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? fmaf(dp[r], a.drop_scale, ndelta) : ndelta;
-            ds[hb][r] = ps * e;
+          for (int r = 0; r < 4; ++r) ps[r] = __builtin_amdgcn_exp2f(ps[r]);
+          float4v e = dp + nd4;
+          if (drop) {
+            float4v keep;  // drop_scale for the kept probabilities, 0 for the dropped ones
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              keep[r] = attn_keep(rseed, kmul0 + (uint32_t)(kb16 + r) * ATT_GOLD, thr_hi) ? a.drop_scale : 0.f;
+            e = dp * keep + nd4;
           }
+          ds[hb] = ps * e;
         }
         const short8 dsf = pack_pair<T>(ds[0], ds[1]);
 #pragma unroll
@@ -726,7 +766,7 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
   for (int db = 0; db < 4; ++db) { dk_[db] = float4v{0.f, 0.f, 0.f, 0.f}; dv_[db] = float4v{0.f, 0.f, 0.f, 0.f}; }
   if (kv_active && !PDT_ATT_NOCOMPUTE) {
     const uint32_t kmul = (uint32_t)key * ATT_GOLD;
-    const float dsc2 = a.drop_scale * a.scale;
+    const float4v k2v = splat4(k2), mb4 = splat4(mbk);
 #pragma unroll
     for (int qb = 0; qb < NPB; ++qb) {
       if (qb < nqb) {
@@ -742,18 +782,19 @@ void attn_bwd_fused128_kernel(AttnArgs a, float* __restrict__ dbias) {
           const float4v ls = *reinterpret_cast<const float4v*>(lse_s + q16 + 4 * g);
           const float4v nde = *reinterpret_cast<const float4v*>(del_s + q16 + 4 * g) * (-a.scale);
           const uint4v sd = *reinterpret_cast<const uint4v*>(seed_s + q16 + 4 * g);
+          float4v p = packed4(sc * k2v + (mb4 + ls));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], k2, mbk - ls[r]));
-            float pd = p, e = fmaf(dp[r], a.scale, nde[r]);
-            if (drop) {
-              const bool keep = attn_keep(sd[r], kmul, thr_hi);
-              pd = keep ? p * a.drop_scale : 0.f;
-              e = keep ? fmaf(dp[r], dsc2, nde[r]) : nde[r];
-            }
-            pp[hb][r] = pd;
-            ds[hb][r] = p * e;
+          for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+          float4v pd = p, e = dp * a.scale + nde;
+          if (drop) {
+            float4v keep;  // drop_scale for the kept probabilities, 0 for the dropped ones
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = attn_keep(sd[r], kmul, thr_hi) ? a.drop_scale : 0.f;
+            pd = p * keep;
+            e = dp * (keep * a.scale) + nde;
           }
+          pp[hb] = pd;
+          ds[hb] = p * e;
         }
         const short8 pf = pack_pair<T>(pp[0], pp[1]);
         const short8 dsf = pack_pair<T>(ds[0], ds[1]);
