@@ -76,9 +76,9 @@ def main() -> None:
                     help="single GPU only: run the data-parallel machinery anyway (1-rank RCCL group, every bucket "
                          "all-reduce really issued on RCCL's stream) to see what the gradient path costs besides the wire")
     ap.add_argument("--gemm-persist", type=int, default=None, choices=[0, 1, 2],
-                    help="persistent launches of the large GEMMs (256 workgroups walk the output tiles): 0 never, 1 from 4 "
-                         "tiles per workgroup, 2 from 2.  Default: 1 on one GPU, 0 in multi-rank runs, where one workgroup "
-                         "per tile lets the communication kernels of other streams onto the CUs at tile granularity")
+                    help="persistent launches of the large GEMMs (256 workgroups draw the output tiles from ticket counters): "
+                         "0 never (one workgroup per tile), 1 from 4 tiles per workgroup (default, single- and multi-rank), "
+                         "2 from 2")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (all micro-batches + optimizer) in one hipGraph (single GPU only)")
     args = ap.parse_args()

@@ -30,7 +30,7 @@ for n in 1 2 4 8; do
   python -c 'import sys; n,v,b=int(sys.argv[1]),float(sys.argv[2]),float(sys.argv[3]); print(f"# {n} GPU(s): {v:.1f} samples/s, scaling efficiency {100*v/(n*b):.1f} %")' "$n" "$v" "$base"
 done
 if [ "${PDT_SWEEP_REF:-1}" = "1" ] && [ "$NGPU" -ge 2 ]; then
-  for cfg in "--batch 96" "--batch 96 --accum 12" "--batch 96 --comm-dtype bf16" "--batch 96 --gemm-persist 1"; do
+  for cfg in "--batch 96" "--batch 96 --accum 12" "--batch 96 --comm-dtype bf16"; do
     echo "# reference batch: $cfg"
     one=$(python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" ${cfg/--comm-dtype bf16/} "$@")
     all=$(python -m torch.distributed.run --nnodes=1 --nproc-per-node "$NGPU" --master-addr 127.0.0.1 --master-port 29640 \
@@ -52,6 +52,7 @@ fi
 if [ "${PDT_SWEEP_COMM:-0}" = "1" ] && [ "$NGPU" -ge 2 ]; then
   # gradient-transport matrix on all GPUs: who drives RCCL, how a bucket is reduced, wire dtype, persistent GEMMs
   # next to the communication kernels, RCCL channel count.  Compare "value" and "comm_exposed_ms_per_step".
+  # (default batch: the persistent launches only exist from 1024 output tiles per GEMM, i.e. not at 96 samples per GPU)
   run() { # run <label> <env assignments...> -- <bench flags...>
     local label=$1; shift; local envs=()
     while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
@@ -63,7 +64,7 @@ if [ "${PDT_SWEEP_COMM:-0}" = "1" ] && [ "$NGPU" -ge 2 ]; then
   run "torch process group" PDT_X=0 -- --comm c10d
   run "reduce-scatter + all-gather buckets" PDT_X=0 -- --comm-algo rs_ag
   run "bf16 on the wire" PDT_X=0 -- --comm-dtype bf16
-  run "persistent GEMM launches next to the collectives" PDT_X=0 -- --gemm-persist 1
+  run "one workgroup per GEMM tile instead of persistent launches next to the collectives" PDT_X=0 -- --gemm-persist 0
   run "AdamW per bucket as the buckets land (bf16)" PDT_X=0 -- --dtype bf16
   run "AdamW after the last bucket (bf16)" PDT_ADAMW_PER_BUCKET=0 -- --dtype bf16
   for ch in 8 16 32; do run "RCCL channels pinned to $ch" NCCL_MIN_NCHANNELS=$ch NCCL_MAX_NCHANNELS=$ch --; done

@@ -100,13 +100,12 @@ class Engine:
             self.distributed_type = DistributedType.NO
         else:
             self.distributed_type = DistributedType.MULTI_GPU if on_gpu else DistributedType.MULTI_CPU
-        if self.native and dist.is_initialized() and dist.get_world_size() > 1 and "PDT_GEMM_PERSIST" not in os.environ:
-            # multi-rank runs share the CUs with the communication kernels of other streams (bucket all-reduces
-            # during backward, pipeline send/recv): the large GEMMs are launched one workgroup per output tile, so
-            # those kernels get in at tile granularity instead of waiting for a whole persistent GEMM
-            from .ops import native as _native
-
-            _native().set_gemm_persistent(0)
+        # Persistent launches of the large GEMMs (256 workgroups drawing output tiles from ticket counters) stay on in
+        # multi-rank runs: a workgroup never waits for anything but its counter, so communication kernels of other streams
+        # (bucket all-reduces, pipeline send/recv) at worst start when the next GEMM workgroup retires, and GEMM workgroups
+        # that find their CU taken simply leave their tiles to the others.  Measured in the 1-rank RCCL rehearsal (every
+        # bucket collective really issued): 262.7 ms per step with persistent launches, 266.7 ms with one workgroup per
+        # tile (PDT_GEMM_PERSIST=0 / bench.py --gemm-persist 0, a row of bench/scale_sweep.sh).
         self.seed = seed
         self.comm_dtype = comm_dtype
         # gradient all-reduce through c10d's "nccl" backend (default) or the framework's own RcclComm ("rccl")

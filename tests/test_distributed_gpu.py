@@ -394,10 +394,10 @@ def _torchrun_bench(extra, port=None, timeout=240, bare=False):
 
 
 def test_bench_two_ranks_share_the_gpu_data_parallel_and_pipeline():
-    """bench.py under the launcher with two ranks on the one GPU (gloo rehearsal; multi-rank runs launch every GEMM with
-    one workgroup per tile - the Engine switches the persistent launch off): data parallel (bucket reducer staged
+    """bench.py under the launcher with two ranks on the one GPU (gloo rehearsal; multi-rank runs keep the persistent GEMM launches of
+    the single-GPU run): data parallel (bucket reducer staged
     through the host) and DP x 2-stage pipeline in fp16 (overflow flag agreed across the stages)."""
-    assert_mode = 0  # what bench.py must report as gemm_persistent_mode for a multi-rank run
+    assert_mode = 1  # what bench.py must report as gemm_persistent_mode for a multi-rank run (the single-GPU default)
     dp = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"])
     assert dp["n_gpus"] == 2 and dp["config"]["parallelism"] == "dp2" and dp["value"] > 0
     assert dp["config"]["gemm_persistent_mode"] == assert_mode and dp["replicas_bit_equal"] is True
