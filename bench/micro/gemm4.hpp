@@ -63,6 +63,23 @@
 #ifndef PDT_G4_SKEW
 #define PDT_G4_SKEW 8
 #endif
+// MFMA slots per fragment read in the two read sections (1: the 16 reads of a section go with its first 16 MFMAs; R: with
+// its first 16 R, one read every R slots).  The four waves issue their reads in the same window and share one LDS port
+// (128 B/clk): at one 1-KiB read per wave and 16-cycle slot they ask for twice what it delivers, the reads queue, and
+// with one wave per SIMD a queued read holds up the MFMAs behind it.  The barrier that frees the buffer follows the last
+// read, so PDT_G4_FIRST must be at least 16 R.
+#ifndef PDT_G4_RSPREAD
+#define PDT_G4_RSPREAD 1
+#endif
+// MFMA slot in front of which a wave waits for its fragment reads of the top section and joins the barrier that frees
+// the buffer (default: right behind the last read, which then costs a full LDS latency; later slots give the reads the
+// MFMAs in between to return)
+#ifndef PDT_G4_BARRIER
+#define PDT_G4_BARRIER (16 * PDT_G4_RSPREAD)
+#endif
+static_assert(PDT_G4_RSPREAD >= 1 && PDT_G4_RSPREAD <= 4 && PDT_G4_BARRIER >= 16 * PDT_G4_RSPREAD && PDT_G4_BARRIER <= 64 &&
+              PDT_G4_FIRST >= PDT_G4_BARRIER, "read spread / barrier slot / first DMA slot");
+static_assert(PDT_G4_FIRST + 15 * PDT_G4_GAP < 128, "the 16 DMA pieces of a K-tile must fit into its MFMA slots");
 // pieces issued before the mid-tile wait (slots < 64): ceil((64 - FIRST) / GAP), at most 16
 #define PDT_G4_PIECES_BEFORE_MID ((64 - PDT_G4_FIRST + PDT_G4_GAP - 1) / PDT_G4_GAP > 16 ? 16 : (64 - PDT_G4_FIRST + PDT_G4_GAP - 1) / PDT_G4_GAP)
 
@@ -271,10 +288,11 @@ struct Gemm4 {
         const char* nbuf = smem + ((t + 1) & 1) * BUF_BYTES;
         // ---- top: F1 <- tile t, paired with the first MFMAs of k-step 0
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          PDT_FRAG4(c, 1, buf);
+        for (int c = 0; c < PDT_G4_BARRIER; ++c) {
+          if (c < 16 * PDT_G4_RSPREAD && c % PDT_G4_RSPREAD == 0) PDT_FRAG4(c / PDT_G4_RSPREAD, 1, buf);
           if (PDT_ABLATE4 == 8) { if ((c & 1) == 0) mfma32_acc(fb[0][(c >> 1) & 7], fa[0][0], acc32[(c >> 1) & 15]); }
           else PDT_MFMA4(c, 0);
+          if ((PDT_G4_RSPREAD > 1 || PDT_G4_BARRIER > 16) && c % PDT_G4_RSPREAD == PDT_G4_RSPREAD - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -302,7 +320,7 @@ struct Gemm4 {
     } else if ((S) < 64) PDT_MFMA4((S), 0); else PDT_MFMA4((S) - 64, 1);                     \
   } while (0)
 #pragma unroll
-        for (int sl = 16; sl < 64; ++sl) {
+        for (int sl = PDT_G4_BARRIER; sl < 64; ++sl) {
           PDT_SLOT4(sl);
           if ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -312,12 +330,13 @@ struct Gemm4 {
         skew(wave);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          PDT_FRAG4(c, 0, nbuf);
+        for (int c = 0; c < 16 * PDT_G4_RSPREAD; ++c) {
+          if (c % PDT_G4_RSPREAD == 0) PDT_FRAG4(c / PDT_G4_RSPREAD, 0, nbuf);
           PDT_SLOT4(64 + c);
+          if (PDT_G4_RSPREAD > 1 && c % PDT_G4_RSPREAD == PDT_G4_RSPREAD - 1) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int sl = 80; sl < 128; ++sl) {
+        for (int sl = 64 + 16 * PDT_G4_RSPREAD; sl < 128; ++sl) {
           PDT_SLOT4(sl);
           if ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
