@@ -179,7 +179,7 @@ class ParamArena:
             max_elems = int(float(os.environ.get("PDT_MAX_BUCKET_MB", "64")) * (1 << 20) / 4)
         if tail_elems is None:
             tail_elems = int(float(os.environ.get("PDT_TAIL_BUCKET_MB", "32")) * (1 << 20) / 4)
-        unit = 8 * ALIGN  # piece boundaries: aligned like parameters, and a multiple of any rank count up to 8
+        unit = 8 * ALIGN  # piece sizes: a multiple of the parameter alignment and of any rank count up to 8 (512 elements)
         old_bounds, old_expected = self.bucket_bounds, self.bucket_segments
         nb = len(old_bounds) - 1
         bounds, expected, parts = [0], [], []

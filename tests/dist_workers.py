@@ -25,8 +25,13 @@ def _global_batch(n=8, s=12):
                 labels=torch.randint(0, 2, (n,), generator=g))
 
 
-def dp_grads_match_big_batch(rank, world):
-    """DP gradients (average over ranks of per-shard mean loss) == gradients of the whole batch on one process."""
+def dp_grads_match_big_batch(rank, world, split_mb=None):
+    """DP gradients (average over ranks of per-shard mean loss) == gradients of the whole batch on one process.
+    `split_mb`: cut every bucket into pieces of at most that many MB (half of it for the last bucket of backward)."""
+    if split_mb is not None:
+        import os
+
+        os.environ["PDT_MAX_BUCKET_MB"], os.environ["PDT_TAIL_BUCKET_MB"] = str(split_mb), str(split_mb / 2)
     eng = Engine(cpu=True, min_bucket_mb=0.05)
     model = _model(seed=rank)  # different init per rank: prepare() must broadcast rank 0's weights
     model = eng.prepare(model)
@@ -45,7 +50,8 @@ def dp_grads_match_big_batch(rank, world):
         worst = max(worst, (p.grad - q.grad).abs().max().item())
     order = model.reducer.launch_order()
     nb = model.reducer.num_buckets()
-    return {"worst": worst, "order": list(order), "nb": nb, "stats": dict(model.reducer.stats())}
+    return {"worst": worst, "order": list(order), "nb": nb, "stats": dict(model.reducer.stats()),
+            "pieces": [len(s.buckets) for s in inner.arena.segments]}
 
 
 def dp_no_sync_accumulation(rank, world):

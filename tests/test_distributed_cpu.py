@@ -27,6 +27,18 @@ def test_dp_gradients_equal_single_process_big_batch(world):
     assert res[0]["order"] == res[1]["order"]
 
 
+def test_dp_gradients_with_buckets_cut_into_pieces():
+    """Buckets larger than the cap are cut into several collectives that all wait for the same segments (a piece does not
+    follow parameter boundaries; the last bucket of backward - the embedding tables - gets the smaller cap): the
+    reduced gradients are still the big-batch gradients and the pieces are launched in arena order."""
+    plain = run_distributed(W.dp_grads_match_big_batch, 2)
+    res = run_distributed(W.dp_grads_match_big_batch, 2, args=(0.05,))
+    for r in res:
+        assert r["worst"] < 1e-6
+        assert r["nb"] > plain[0]["nb"] and max(r["pieces"]) >= 2 and r["pieces"][-1] >= 2, (r["nb"], r["pieces"])
+        assert r["order"] == list(range(r["nb"])) and r["stats"]["collectives"] == r["nb"]
+
+
 def test_dp_no_sync_accumulates_locally_then_reduces_once():
     for r in run_distributed(W.dp_no_sync_accumulation, 2):
         assert r["no_sync_kept_local"]

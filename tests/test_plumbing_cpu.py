@@ -214,6 +214,33 @@ def test_arena_layout_views_and_buckets():
     assert arena.grad.abs().sum() == 0
 
 
+def test_arena_cuts_oversized_buckets_into_aligned_pieces():
+    """Every bucket above the cap becomes several pieces (the last bucket of backward has the smaller cap): contiguous,
+    covering the arena, boundaries aligned like parameters (64 elements), pieces of one bucket equal multiples of 512
+    elements (divisible by any rank count up to 8) but for the last, none larger than its cap plus that unit, and every
+    segment knows all the pieces that hold its gradients."""
+    model = build_model("bert-tiny")
+    whole = ParamArena(build_model("bert-tiny"), torch.device("cpu"), min_bucket_elems=1 << 14, max_bucket_elems=1 << 30,
+                       tail_bucket_elems=1 << 30)
+    arena = ParamArena(model, torch.device("cpu"), min_bucket_elems=1 << 14, max_bucket_elems=1 << 15, tail_bucket_elems=1 << 13)
+    b = arena.bucket_bounds
+    assert b[0] == 0 and b[-1] == arena.numel and all(x < y for x, y in zip(b, b[1:]))
+    assert len(b) > len(whole.bucket_bounds) and set(whole.bucket_bounds) <= set(b)  # cuts only add boundaries
+    assert all(x % 64 == 0 for x in b)
+    sizes = [y - x for x, y in zip(b, b[1:])]
+    assert max(sizes[:-1]) <= (1 << 15) + 512 and sizes[-1] <= (1 << 13) + 512
+    assert len(arena.bucket_segments) == len(sizes)
+    covered = set()
+    for seg, ref in zip(arena.segments, whole.segments):
+        assert seg.bucket == seg.buckets[0] and list(seg.buckets) == list(range(seg.buckets[0], seg.buckets[-1] + 1))
+        lo, hi = b[seg.buckets[0]], b[seg.buckets[-1] + 1]
+        assert (lo, hi) == (whole.bucket_bounds[ref.bucket], whole.bucket_bounds[ref.bucket + 1])  # its original bucket
+        assert all(sizes[k] % 512 == 0 for k in seg.buckets[:-1])
+        covered.update(seg.buckets)
+    assert covered == set(range(len(sizes)))
+    assert len(arena.segments[-1].buckets) >= 2  # the embedding tables: the tail cap applies
+
+
 # ------------------------------------------------------------------------------------------- HF parity
 def _hf_bert(cfg):
     from transformers import BertConfig, BertForSequenceClassification
