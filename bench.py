@@ -288,8 +288,9 @@ def bench_pipeline(args, world: int, comm) -> None:
         raise SystemExit("--pp 2 needs an even number of ranks")
     env, device = launch.init_distributed()
     mesh = ParallelMesh(world, env.rank, pp=2).build_groups()
+    # (update_in_backward=False, like the pipeline recipe: the optimizer runs after the schedule's last backward)
     eng = Engine(fp16=args.dtype == "fp16", bf16=args.dtype == "bf16", seed=42, comm_dtype=comm, comm_backend=args.comm,
-                 process_group=mesh.dp_group)
+                 process_group=mesh.dp_group, update_in_backward=False)
     if eng.device.type != "cuda":
         raise SystemExit("bench.py needs a GPU")
     model_cfg = preset(args.model)
