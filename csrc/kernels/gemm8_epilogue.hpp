@@ -49,9 +49,14 @@ struct FastEpilogue8 {
   }
 
   // ---- plain / bias / bias + GELU: math on the accumulators, 16-bit transpose ----------------------------------
-  // Staging image of one row-block pair: 32 rows x 64 columns x 2 B, 128-B rows, 16-B chunks XOR-swizzled by row & 7.
+  // Staging image of one row-block pair: 32 rows x 64 columns x 2 B, 128-B rows, 16-B chunks XOR-swizzled by row & 7, and
+  // the two 8-B halves of every chunk swapped in rows 8-15 of each 16-row block.
   // Accumulator layout: lane (lm = lane & 15, lg = lane >> 4) holds columns lg*4 .. +3 of row lm of every 16 x 16 block.
   // Row layout: lane (rsub = lane >> 3, jc = lane & 7) holds the 8 columns of chunk jc of row it*8 + rsub.
+  // The 16 lanes that write together (one lg, rows lm = 0 .. 15) hit 8 distinct chunks through the XOR; without the half
+  // swap rows lm and lm + 8 would write the same 8 bytes' banks (a 2-way conflict on every transposed write: measured
+  // as 7-12 % of the kernel's LDS cycles), with it the 16 lanes cover all 32 banks once.  A row read fetches whole
+  // chunks, so the reader just swaps the halves back in registers - for odd `it`, known at compile time.
   template <int EPI>
   static __device__ __forceinline__ void run16(const PdtGemm& g, float4v (&acc)[8][4], char* stg, int m_w, int n_w, int lane) {
     constexpr bool has_bias = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU;
@@ -67,7 +72,7 @@ struct FastEpilogue8 {
       }
     }
     const int key_w = (lg >> 1) ^ (lm & 7);
-    char* wbase = stg + lm * 128 + (lg & 1) * 8;
+    char* wbase = stg + lm * 128 + ((lg & 1) ^ (lm >> 3)) * 8;
     const char* rbase = stg + rsub * 128 + ((jc ^ rsub) << 4);
     const __amdgpu_buffer_rsrc_t rc = rsrc_of(g.C, g.M, g.ldc, g.N);
     const __amdgpu_buffer_rsrc_t ra = rsrc_of(gelu ? g.aux : g.C, g.M, gelu ? g.ldaux : g.ldc, g.N);
@@ -102,12 +107,14 @@ struct FastEpilogue8 {
       const char* r = rbase + ((!gelu && (ip & 1)) ? 4096 : 0);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const uint4v c = *reinterpret_cast<const uint4v*>(r + it * 1024);
+        uint4v c = *reinterpret_cast<const uint4v*>(r + it * 1024);
+        if (it & 1) c = uint4v{c[2], c[3], c[0], c[1]};  // rows 8-15 of a block: halves were stored swapped
         const uint32_t row = (uint32_t)(pair_row(ip) + it * 8);
         __builtin_amdgcn_raw_buffer_store_b128(c, rc, (int)(lane_c + base_c + row * step_c), 0, 0);
         if (gelu) {
           // gelu'(pre-activation): not read again before the backward pass, keep it out of the caches
-          const uint4v a = *reinterpret_cast<const uint4v*>(r + 4096 + it * 1024);
+          uint4v a = *reinterpret_cast<const uint4v*>(r + 4096 + it * 1024);
+          if (it & 1) a = uint4v{a[2], a[3], a[0], a[1]};
           __builtin_amdgcn_raw_buffer_store_b128(a, ra, (int)(lane_a + base_a + row * step_a), 0, 2);
         }
       }
