@@ -29,6 +29,10 @@ import os
 # dmabuf IPC (the only mode the host driver of these nodes supports) for RCCL / cross-process GPU memory:
 # must be in the environment before the HIP runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if "--graph" in __import__("sys").argv:
+    # graph replays want HIP's default of 4 hardware queues (16, the package default, makes them 2.4x slower: see
+    # utils/graph.py); the count is fixed when the HIP runtime starts, i.e. before the package is imported
+    os.environ.setdefault("PDT_HW_QUEUES", "0")
 import sys
 import time
 

@@ -18,8 +18,9 @@ def _hardware_queues() -> None:
     the weight-gradient lane, the communication stream, RCCL's own streams and the micro-batch lanes: with 4 queues which
     two of them end up sharing depends on creation order - measured on MI355X (BERT-large, 96 samples per step, 1-rank RCCL
     rehearsal): 36.0 ms per step with 4 queues (weight-gradient lane serialised behind the compute stream), 40.0 ms with 8,
-    34.4 ms with 16, where every stream has a queue of its own; no configuration got slower with 16.  ``PDT_HW_QUEUES``
-    sets another count (0: leave the environment alone).  Read by the HIP runtime when it initialises."""
+    34.4 ms with 16, where every stream has a queue of its own; no eager configuration got slower with 16.  hipGraph
+    replays do (96 -> 235 ms for the captured 12 x 8 step: utils/graph.py warns; ``bench.py --graph`` keeps the default).
+    ``PDT_HW_QUEUES`` sets another count (0: leave the environment alone).  Read by the HIP runtime when it initialises."""
     want = int(_os.environ.get("PDT_HW_QUEUES", "16"))
     if want > 0 and int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < want:
         _os.environ["GPU_MAX_HW_QUEUES"] = str(min(want, 32))

@@ -64,6 +64,14 @@ class GraphedStep:
         if window == "overlap" and os.environ.get("PDT_GRAPH_OVERLAP_WINDOW") != "1":
             raise RuntimeError(OVERLAP_REFUSAL)
         self.window = window
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) > 4:
+            import warnings
+
+            # measured on ROCm 7.2, 12 x 8 samples of BERT-large, one-stream capture: 96 ms per replayed step with HIP's
+            # default of 4 hardware queues, 235 ms with the 16 this package asks for at import (the graph executor
+            # spreads the weight-gradient branches over more queues and pays for every cross-queue dependency)
+            warnings.warn("hipGraph replays are ~2.4x slower with more than 4 hardware queues: start the process with "
+                          "PDT_HW_QUEUES=0 (before the package is imported) when steps are replayed from graphs")
         if engine.num_processes != 1:
             raise RuntimeError("GraphedStep captures single-process steps only")
         if engine.device.type != "cuda":
