@@ -207,8 +207,19 @@ constexpr int ATT_IMG_BYTES = 4 * ATT_CHUNK * 128;
 // DBUF: two image pairs, chunk c+1 staged under chunk c (sequences of more than one chunk); without it one pair,
 // filled at the top of every chunk (the single-chunk launch: nothing to stage ahead, and the simpler loop measured
 // 10 % faster there)
+// (experiments) minimum waves per SIMD the forward's register allocation must allow; 0: the compiler's choice (120
+// registers, two workgroups per CU).  Measured at batch 1024: 6 (80 registers, three workgroups per CU, 44 spilled
+// registers) takes 431 us per layer instead of 255 us - the spills go through scratch memory in a memory-bound kernel.
+#ifndef PDT_ATT_FWD_WAVES_EU
+#define PDT_ATT_FWD_WAVES_EU 0
+#endif
+#if PDT_ATT_FWD_WAVES_EU > 0
+#define PDT_ATT_FWD_OCC __attribute__((amdgpu_waves_per_eu(PDT_ATT_FWD_WAVES_EU, 8)))
+#else
+#define PDT_ATT_FWD_OCC
+#endif
 template <typename T, bool DROP, bool DBUF>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) PDT_ATT_FWD_OCC void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* mbias = reinterpret_cast<float*>(smem + (DBUF ? ATT_IMG_BYTES : ATT_IMG_BYTES / 2));
   const int tid = threadIdx.x, lane = tid & 63;
