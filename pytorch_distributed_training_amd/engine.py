@@ -183,7 +183,10 @@ class Engine:
             dps = [m for m in self._models if isinstance(m, DataParallel) and m.arena is self._arena]
             # (the overflow check rides behind the bucket all-reduces when the reducer can do it)
             fused.grads_checked_by_reducer = bool(dps) and all(m.attach_scaler(self.scaler) for m in dps)
-            if self.update_in_backward and len(dps) == 1 and dps[0].auto_arm and not dps[0].manual_finish:
+            # (native path only: there a bucket is marked after the whole layer's backward - data gradients included - has
+            # been enqueued; a per-parameter autograd hook may fire before the data gradient that still reads the weight)
+            if (self.update_in_backward and len(dps) == 1 and dps[0].native_mode and dps[0].auto_arm
+                    and not dps[0].manual_finish):
                 fused.attach_reducer(dps[0].reducer)
             self._fused.append(fused)
             return EngineOptimizer(fused, self)
