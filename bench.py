@@ -275,6 +275,14 @@ def _teardown() -> None:
     sys.stderr.flush()
     torch.cuda.synchronize()
     multi = dist.get_world_size() > 1
+    if multi:
+        # the measurement is complete and printed: a teardown handshake that does not return (a peer already gone) must
+        # not turn the run into a hang - leave after 30 s whatever destroy_process_group() is doing
+        import threading
+
+        t = threading.Timer(30.0, lambda: os._exit(0))
+        t.daemon = True
+        t.start()
     dist.destroy_process_group()
     if multi:  # (a 1-rank rehearsal exits normally: a profiler attached to it writes its output at exit)
         os._exit(0)
