@@ -367,7 +367,7 @@ print("ADAMW_PER_BUCKET_OK")
     _run_snippet(code, "ADAMW_PER_BUCKET_OK")
 
 
-def _torchrun_bench(extra, port=None, timeout=240, bare=False):
+def _torchrun_bench(extra, port=None, timeout=240, bare=False, world=2):
     """bench.py with two ranks: under the launcher (the driver's command line), or - `bare` - as plain
     ``python bench.py --gpus 2`` with no launcher environment, where the script starts its own rank processes."""
     import json
@@ -376,11 +376,11 @@ def _torchrun_bench(extra, port=None, timeout=240, bare=False):
     from pytorch_distributed_training_amd.launch import find_free_port
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    tail = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1"] + extra
     if bare:
         cmd = [sys.executable] + tail
     else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(port or find_free_port())] + tail
     env = dict(os.environ, PDT_HANG_DUMP="150")
     if bare:  # no launcher environment at all: that is the point
@@ -414,3 +414,12 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     out = _torchrun_bench(["--model", "bert-base-cased", "--batch", "128"], bare=True)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and out["replicas_bit_equal"] is True
+
+
+def test_bench_eight_ranks_share_the_gpu():
+    """The driver's 8-rank command line (torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8) rehearsed with
+    eight processes on the one GPU over gloo at BERT-base size: rank arithmetic, 8-way replica verification, the bucket
+    list of eight ranks, the MAX over ranks of the timed region and the bit-equality check of all eight replicas."""
+    out = _torchrun_bench(["--model", "bert-base-cased", "--batch", "32"], world=8, timeout=400)
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 256
+    assert out["value"] > 0 and out["replicas_bit_equal"] is True and out["last_step_loss"] == out["last_step_loss"]
